@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Benchmark of the MSM witness path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload msm|lhs] [--logn L] [--curve bn254_g1|grumpkin]
+
+One "step" = one full n-point MSM (digits -> bucket sort -> bucket accumulation -> bucket
+reduction -> host Horner) over synthetic inputs that are resident in HBM before the timed
+region.  Default workload: 2^24-point BN254 G1 MSM with full-width scalars (BASELINE.json
+configs[2], the size BASELINE.json's target sentence names); `--workload lhs --logn 20` runs
+configs[1] (2^20 points, negabase w=4 i.e. base 16, half-width scalars).  For N > 1 the same
+MSM is sharded by Pippenger window over the ranks (strong scaling) with one all-gather of the
+per-window partial records over RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_accum1, the bucket
+accumulation) at the ALGORITHMIC 96 B per scalar-point pair against the 8 TB/s HBM peak, from
+HIP-event timings taken on the library's own stream; `cpu_baseline` times the oracle's
+restatement of halo2 best_multiexp on the host cores over a bounded sample of the same inputs
+and checks the GPU result on that sample bit-exactly.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ORDER = {
+    "bn254_g1": 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
+    "grumpkin": 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47,
+}
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_GINSTR = 35700.0       # measured lane-instructions/s, profiles/r01_valu_rates_microbench.txt
+BYTES_PER_PAIR = 96              # 32 B scalar + 64 B affine point
+
+
+def gen_scalars(n: int, modulus: int, seed: int) -> np.ndarray:
+    """n x 32 B canonical LE scalars: 256 random bits reduced mod `modulus` (>= 2^253) by
+    conditional subtraction, or masked below a small modulus's bit length then rejected-by-subtract."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    limbs = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    bl = modulus.bit_length()
+    if bl < 256:
+        top = (bl - 1) // 64
+        limbs[:, top + 1:] = 0
+        limbs[:, top] &= np.uint64((1 << (bl - 64 * top)) - 1)
+    m = np.array([(modulus >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+    for _ in range(8):
+        ge = np.ones(n, bool); decided = np.zeros(n, bool)
+        for i in (3, 2, 1, 0):
+            gt = limbs[:, i] > m[i]; lt = limbs[:, i] < m[i]
+            ge = np.where(~decided & lt, False, ge)
+            decided |= gt | lt
+        if not ge.any():
+            break
+        borrow = np.zeros(n, np.uint64)
+        for i in range(4):
+            a = limbs[:, i]
+            t = a - m[i]
+            b1 = (a < m[i]).astype(np.uint64)
+            t2 = t - borrow
+            b2 = (t < borrow).astype(np.uint64)
+            limbs[:, i] = np.where(ge, t2, a)
+            borrow = b1 | b2
+    return limbs.view(np.uint8).reshape(n, 32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["msm", "lhs"], default="msm")
+    ap.add_argument("--logn", type=int, default=None)
+    ap.add_argument("--curve", choices=["bn254_g1", "grumpkin"], default="bn254_g1")
+    ap.add_argument("--base", type=int, default=16)
+    ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 of the cpu_baseline sample size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    logn = args.logn if args.logn is not None else (24 if args.workload == "msm" else 20)
+    n = 1 << logn
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from halo2_liam_eagen_msm_amd import Context
+    from halo2_liam_eagen_msm_amd import dist as ldist
+    ctx = Context(local_rank)
+    curve = args.curve
+    cid = {"bn254_g1": 0, "grumpkin": 1}[curve]
+    order = ORDER[curve]
+
+    # ---- synthetic inputs, identical on every rank (points replicated per GPU) ----
+    t_in = time.time()
+    modulus = order if args.workload == "msm" else math.isqrt(order)
+    scalars = gen_scalars(n, modulus, 0x5EED0000 + logn)
+    d_scalars = ctx.to_device(scalars)
+    # Q = a fixed curve point (generator); P_i = (i+1) Q generated on the device
+    q = np.zeros(8, np.uint64)
+    fp = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47 if cid == 0 else ORDER["bn254_g1"]
+    gx, gy = (1, 2) if cid == 0 else (1, 0x2CF135E7506A45D632D270D45F1181294833FC48D823F272C)
+    q[:4] = np.frombuffer(((gx << 256) % fp).to_bytes(32, "little"), np.uint64)
+    q[4:] = np.frombuffer(((gy << 256) % fp).to_bytes(32, "little"), np.uint64)
+    d_points = ctx.gen_walk(cid, q, n)
+    t_in = time.time() - t_in
+
+    def step():
+        if args.workload == "msm":
+            if world == 1:
+                return ctx.msm_device(cid, d_scalars.ptr, d_points.ptr, n)
+            return ldist.sharded_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, world, rank, dev)
+        if world == 1:
+            return ctx.lhs_msm_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True)[0]
+        return ldist.sharded_lhs_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, args.base, world, rank, dev)[0]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc_ms = 0.0; tot_ms = 0.0; launches = 0
+    for _ in range(args.steps):
+        result = step()
+        tt, ta, nl = ctx.last_timing()
+        acc_ms += ta; tot_ms += tt; launches += nl
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n * args.steps / elapsed
+        # dominant kernel: k_accum1 (one launch per window group; one group at these sizes)
+        launches = max(launches, 1)
+        accum_ms = acc_ms / launches
+        # pairs one launch processes: all n pairs, for this rank's share of the windows
+        achieved = BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "kernel": "k_accum1", "kernel_ms": round(accum_ms, 4), "pipeline_device_ms": round(tot_ms / args.steps, 4),
+                    "note": "integer-ALU-bound path: 96 algorithmic B/pair vs 8 TB/s HBM; see DESIGN.md for the VALU roofline"}
+        out = {
+            "metric": "BN254 G1 MSM scalar-point-pairs/s" if curve == "bn254_g1" else "Grumpkin MSM scalar-point-pairs/s",
+            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
+            "config": {"workload": ("%s MSM, 2^%d points, full-width scalars" % (curve, logn)) if args.workload == "msm"
+                       else ("%s compute_lhs_witness MSM core, 2^%d points, negabase B=%d (w=4), half-width scalars" % (curve, logn, args.base)),
+                       "n": n, "curve": curve, "sharding": "pippenger-window x%d" % world, "bit_exact": True,
+                       "input_gen_s": round(t_in, 2)},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args):
+    """Oracle leg (checker + timed CPU baseline, rank 0, N = 1 only): the C restatement of halo2
+    best_multiexp (thread-chunked serial Pippenger) on a bounded sample of the same inputs, all host
+    threads; the GPU result on the same sample must match bit-exactly."""
+    from oracle import cref
+    cores = os.cpu_count() or 1
+    slog = args.cpu_sample_log if args.cpu_sample_log is not None else min(logn, 21)
+    m = 1 << slog
+    pts = d_points.download(np.uint64, m * 64).reshape(-1, 8)
+    sc = np.ascontiguousarray(scalars[:m])
+    t0 = time.perf_counter()
+    ref = cref.best_multiexp(cid, sc, pts, cores)
+    dt = time.perf_counter() - t0
+    ds = ctx.to_device(sc)
+    got = ctx.msm_device(cid, ds.ptr, d_points.ptr, m)
+    ok = cref.jac_to_canonical(cid, got) == cref.jac_to_canonical(cid, ref)
+    if not ok:
+        raise SystemExit("GPU result differs from the CPU oracle on the sample: parity broken")
+    return {"value": round(m / dt, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "first 2^%d pairs of the same inputs, best_multiexp restatement (oracle/c), %.2f s, GPU result on the sample bit-exact" % (slog, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,11 @@
+"""MI355X (gfx950) MSM witness path for Liam Eagen's MSM argument.
+
+`api` mirrors the reference's Rust entry points over the C ABI in include/lemsm.h;
+`dist` shards one MSM by Pippenger window / negabase digit position over the GPUs of a node.
+"""
+from . import _lib  # noqa: F401
+from .api import (  # noqa: F401
+    BN254_G1, GRUMPKIN, Context, DeviceBuffer, LemsmError, LengthMismatch, ScalarOutOfRange, BadBase,
+    best_multiexp, compute_lhs_witness, negbase_decompose, precompute_multiplicities,
+    jacobian_to_canonical, logb_ceil, order, num_digits, id_by_digit, digit_by_id,
+)

@@ -1,0 +1,113 @@
+"""ctypes loader for the C-ABI library (include/lemsm.h).
+
+The product path has NO CPU fallback: if liblemsm.so is missing or no gfx950
+device is usable, loading / context creation raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "liblemsm.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+LEMSM_OK = 0
+LEMSM_ERR_LEN_MISMATCH = 1
+LEMSM_ERR_SCALAR_OUT_OF_RANGE = 2
+LEMSM_ERR_BAD_BASE = 3
+LEMSM_ERR_BAD_CURVE = 4
+LEMSM_ERR_HIP = 5
+LEMSM_ERR_BAD_ARG = 6
+LEMSM_ERR_NOMEM = 7
+LEMSM_ERR_TOO_MANY_DIGITS = 8
+
+BN254_G1 = 0
+GRUMPKIN = 1
+
+# Every symbol include/lemsm.h declares (tests/test_abi.py checks the header against this list
+# and that the built library exports each of them).
+SYMBOLS = [
+    "lemsm_create", "lemsm_destroy", "lemsm_strerror", "lemsm_last_error", "lemsm_set_option",
+    "lemsm_last_timing",
+    "lemsm_msm", "lemsm_msm_bn254_g1", "lemsm_msm_grumpkin", "lemsm_msm_device",
+    "lemsm_msm_plan", "lemsm_msm_partial_device", "lemsm_msm_combine",
+    "lemsm_num_digits", "lemsm_negbase_decompose_batch",
+    "lemsm_lhs_msm", "lemsm_lhs_msm_grumpkin", "lemsm_lhs_msm_bn254_g1", "lemsm_lhs_msm_device",
+    "lemsm_lhs_plan", "lemsm_lhs_partial_device", "lemsm_lhs_combine",
+    "lemsm_precompute_multiplicities",
+    "lemsm_jacobian_to_canonical",
+    "lemsm_device_alloc", "lemsm_device_free", "lemsm_device_upload", "lemsm_device_download",
+    "lemsm_device_gen_walk",
+    "lemsm_debug_montmul", "lemsm_debug_fieldop", "lemsm_debug_pointop",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "lemsm.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.isfile(s)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load liblemsm.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the MSM path has no CPU fallback)"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, u8p, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p
+    i, u32p, szp = ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_size_t)
+    sig = {
+        "lemsm_create": (i, [i, ctypes.POINTER(vp)]),
+        "lemsm_destroy": (None, [vp]),
+        "lemsm_strerror": (ctypes.c_char_p, [i]),
+        "lemsm_last_error": (ctypes.c_char_p, [vp]),
+        "lemsm_set_option": (i, [vp, ctypes.c_char_p, ctypes.c_long]),
+        "lemsm_last_timing": (i, [vp, ctypes.POINTER(ctypes.c_double)]),
+        "lemsm_msm": (i, [vp, i, u8p, u64p, sz, u64p]),
+        "lemsm_msm_bn254_g1": (i, [vp, u8p, u64p, sz, u64p]),
+        "lemsm_msm_grumpkin": (i, [vp, u8p, u64p, sz, u64p]),
+        "lemsm_msm_device": (i, [vp, i, vp, vp, sz, u64p]),
+        "lemsm_msm_plan": (i, [vp, i, sz, u32p, szp]),
+        "lemsm_msm_partial_device": (i, [vp, i, vp, vp, sz, ctypes.c_uint32, ctypes.c_uint32, u8p]),
+        "lemsm_msm_combine": (i, [vp, i, sz, u8p, u64p]),
+        "lemsm_num_digits": (i, [i, ctypes.c_uint8, u32p]),
+        "lemsm_negbase_decompose_batch": (i, [vp, u8p, sz, ctypes.c_uint8, ctypes.c_uint32, u8p]),
+        "lemsm_lhs_msm": (i, [vp, i, u8p, u64p, sz, ctypes.c_uint8, u64p, u64p, szp]),
+        "lemsm_lhs_msm_grumpkin": (i, [vp, u8p, u64p, sz, ctypes.c_uint8, u64p, u64p, szp]),
+        "lemsm_lhs_msm_bn254_g1": (i, [vp, u8p, u64p, sz, ctypes.c_uint8, u64p, u64p, szp]),
+        "lemsm_lhs_msm_device": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, u64p, u64p, szp]),
+        "lemsm_lhs_plan": (i, [i, ctypes.c_uint8, u32p, szp]),
+        "lemsm_lhs_partial_device": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint32, u8p, szp]),
+        "lemsm_lhs_combine": (i, [i, ctypes.c_uint8, u8p, u64p, u64p]),
+        "lemsm_precompute_multiplicities": (i, [vp, i, u64p, sz, ctypes.c_uint8, u64p]),
+        "lemsm_jacobian_to_canonical": (i, [i, u64p, u8p]),
+        "lemsm_device_alloc": (i, [vp, sz, ctypes.POINTER(vp)]),
+        "lemsm_device_free": (i, [vp, vp]),
+        "lemsm_device_upload": (i, [vp, vp, vp, sz]),
+        "lemsm_device_download": (i, [vp, vp, vp, sz]),
+        "lemsm_device_gen_walk": (i, [vp, i, u64p, sz, vp]),
+        "lemsm_debug_montmul": (i, [vp, i, u64p, u64p, u64p, sz]),
+        "lemsm_debug_fieldop": (i, [vp, i, i, u64p, u64p, u64p, sz]),
+        "lemsm_debug_pointop": (i, [vp, i, i, u64p, u64p, u64p, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

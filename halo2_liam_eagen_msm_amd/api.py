@@ -1,0 +1,375 @@
+"""Host-side mirror of the reference's interface for the MSM witness path.
+
+Names, argument meaning and error behaviour follow the reference crate
+(paths relative to /root/reference):
+
+  best_multiexp(coeffs, bases)              halo2::arithmetic::best_multiexp, imported
+                                            src/argument_witness_calc.rs:20, called :144
+  compute_lhs_witness(scalars, pts, base)   src/argument_witness_calc.rs:87-136 (MSM core; returns the
+                                            per-digit carries from which the Rust side builds the
+                                            divisor witnesses of :129)
+  negbase_decompose(x, base)                src/negbase_utils.rs:20-36
+  precompute_multiplicities(pt, base)       src/argument_witness_calc.rs:43-51
+  logb_ceil, order, num_digits              src/argument_witness_calc.rs:32-40,54-56,89-91
+  id_by_digit, digit_by_id                  src/negbase_utils.rs:46-56
+
+Everything that touches points or batches of scalars runs on the GPU through the C ABI
+(include/lemsm.h); there is no CPU fallback.  Data formats are the C ABI's: scalars (n,32)
+uint8 canonical little-endian, field elements 4 x uint64 Montgomery limbs, affine (n,8),
+Jacobian (n,12).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import BN254_G1, GRUMPKIN
+
+ORDER = {
+    BN254_G1: 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
+    GRUMPKIN: 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47,
+}
+CURVE_IDS = {"bn254_g1": BN254_G1, "grumpkin": GRUMPKIN}
+
+
+class LemsmError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"lemsm status {status}: {msg}")
+        self.status = status
+
+
+class LengthMismatch(LemsmError, AssertionError):
+    """reference: assert!(scalars.len() == pts.len(), "incompatible amount of coefficients") (:88)"""
+
+
+class ScalarOutOfRange(LemsmError, AssertionError):
+    """reference: assert!(&x < &sq_p) (:97)"""
+
+    def __init__(self, status, msg, index):
+        super().__init__(status, msg)
+        self.index = index
+
+
+class BadBase(LemsmError, ValueError):
+    pass
+
+
+def _curve_id(curve) -> int:
+    if isinstance(curve, str):
+        return CURVE_IDS[curve]
+    return int(curve)
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _scalars(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.size % 32:
+        raise ValueError("scalars must be n x 32 bytes")
+    return a.reshape(-1, 32)
+
+
+def _limbs(a, width: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.size % width:
+        raise ValueError(f"points must be n x {width} uint64 limbs")
+    return a.reshape(-1, width)
+
+
+class DeviceBuffer:
+    """GPU memory owned by a Context (for inputs that stay resident across calls)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        ctx._check(ctx.lib.lemsm_device_alloc(ctx.h, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.lemsm_device_upload(self.ctx.h, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype=np.uint8, count: Optional[int] = None) -> np.ndarray:
+        nbytes = self.nbytes if count is None else count
+        out = np.empty(nbytes, np.uint8)
+        self.ctx._check(self.ctx.lib.lemsm_device_download(self.ctx.h, _ptr(out), self.ptr, nbytes))
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.lemsm_device_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream + workspace (lemsm_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self.lib.lemsm_create(int(device), ctypes.byref(h))
+        if rc != _lib.LEMSM_OK:
+            raise LemsmError(rc, "lemsm_create failed: no usable gfx950 device (the MSM path has no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lemsm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, bad_index: Optional[int] = None):
+        if rc == _lib.LEMSM_OK:
+            return
+        msg = self.lib.lemsm_last_error(self.h).decode() or self.lib.lemsm_strerror(rc).decode()
+        if rc == _lib.LEMSM_ERR_LEN_MISMATCH:
+            raise LengthMismatch(rc, "incompatible amount of coefficients")
+        if rc == _lib.LEMSM_ERR_SCALAR_OUT_OF_RANGE:
+            raise ScalarOutOfRange(rc, msg, bad_index)
+        if rc == _lib.LEMSM_ERR_BAD_BASE:
+            raise BadBase(rc, msg)
+        raise LemsmError(rc, msg)
+
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.lemsm_set_option(self.h, name.encode(), int(value)))
+
+    def last_timing(self) -> Tuple[float, float, int]:
+        out = (ctypes.c_double * 3)()
+        self._check(self.lib.lemsm_last_timing(self.h, out))
+        return out[0], out[1], int(out[2])
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr: np.ndarray) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
+
+    # ---- best_multiexp -------------------------------------------------------------
+    def msm(self, curve, scalars, points_affine) -> np.ndarray:
+        cid = _curve_id(curve)
+        s = _scalars(scalars)
+        p = _limbs(points_affine, 8)
+        if s.shape[0] != p.shape[0]:
+            raise LengthMismatch(_lib.LEMSM_ERR_LEN_MISMATCH, "incompatible amount of coefficients")
+        out = np.zeros(12, np.uint64)
+        self._check(self.lib.lemsm_msm(self.h, cid, _ptr(s), _ptr(p), s.shape[0], _ptr(out)))
+        return out
+
+    def msm_device(self, curve, d_scalars: int, d_points: int, n: int) -> np.ndarray:
+        out = np.zeros(12, np.uint64)
+        self._check(self.lib.lemsm_msm_device(self.h, _curve_id(curve), d_scalars, d_points, n, _ptr(out)))
+        return out
+
+    def msm_plan(self, curve, n: int) -> Tuple[int, int]:
+        w = ctypes.c_uint32()
+        b = ctypes.c_size_t()
+        self._check(self.lib.lemsm_msm_plan(self.h, _curve_id(curve), n, ctypes.byref(w), ctypes.byref(b)))
+        return w.value, b.value
+
+    def msm_partial_device(self, curve, d_scalars: int, d_points: int, n: int, win_begin: int, win_end: int) -> np.ndarray:
+        _, rec = self.msm_plan(curve, n)
+        out = np.zeros((win_end - win_begin) * rec, np.uint8)
+        self._check(self.lib.lemsm_msm_partial_device(self.h, _curve_id(curve), d_scalars, d_points, n, win_begin, win_end,
+                                                      _ptr(out) if out.size else None))
+        return out
+
+    def msm_combine(self, curve, n: int, partials: np.ndarray) -> np.ndarray:
+        partials = np.ascontiguousarray(partials, np.uint8)
+        out = np.zeros(12, np.uint64)
+        self._check(self.lib.lemsm_msm_combine(self.h, _curve_id(curve), n, _ptr(partials), _ptr(out)))
+        return out
+
+    # ---- negabase ------------------------------------------------------------------
+    def negbase_decompose_batch(self, scalars, base: int, d: int) -> np.ndarray:
+        s = _scalars(scalars)
+        out = np.zeros((s.shape[0], d), np.uint8)
+        self._check(self.lib.lemsm_negbase_decompose_batch(self.h, _ptr(s), s.shape[0], base, d, _ptr(out)))
+        return out
+
+    # ---- compute_lhs_witness MSM core -------------------------------------------------
+    def lhs_msm(self, curve, scalars, pts_jacobian, base: int, want_carries: bool = True):
+        cid = _curve_id(curve)
+        s = _scalars(scalars)
+        p = _limbs(pts_jacobian, 12)
+        if s.shape[0] != p.shape[0]:
+            raise LengthMismatch(_lib.LEMSM_ERR_LEN_MISMATCH, "incompatible amount of coefficients")
+        if not (3 <= base <= 255):
+            raise BadBase(_lib.LEMSM_ERR_BAD_BASE, "base must be in 3..=255")
+        d = num_digits(cid, base)
+        carry = np.zeros(12, np.uint64)
+        carries = np.zeros((d, 12), np.uint64) if want_carries else None
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_lhs_msm(self.h, cid, _ptr(s), _ptr(p), s.shape[0], base, _ptr(carry),
+                                    _ptr(carries) if want_carries else None, ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return carry, carries
+
+    def lhs_msm_device(self, curve, d_scalars: int, d_points_affine: int, n: int, base: int, want_carries: bool = True):
+        cid = _curve_id(curve)
+        d = num_digits(cid, base)
+        carry = np.zeros(12, np.uint64)
+        carries = np.zeros((d, 12), np.uint64) if want_carries else None
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_lhs_msm_device(self.h, cid, d_scalars, d_points_affine, n, base, _ptr(carry),
+                                           _ptr(carries) if want_carries else None, ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return carry, carries
+
+    def lhs_plan(self, curve, base: int) -> Tuple[int, int]:
+        d = ctypes.c_uint32()
+        b = ctypes.c_size_t()
+        self._check(self.lib.lemsm_lhs_plan(_curve_id(curve), base, ctypes.byref(d), ctypes.byref(b)))
+        return d.value, b.value
+
+    def lhs_partial_device(self, curve, d_scalars: int, d_points_affine: int, n: int, base: int, pos_begin: int, pos_end: int) -> np.ndarray:
+        _, rec = self.lhs_plan(curve, base)
+        out = np.zeros(max(pos_end - pos_begin, 0) * rec, np.uint8)
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_lhs_partial_device(self.h, _curve_id(curve), d_scalars, d_points_affine, n, base, pos_begin, pos_end,
+                                               _ptr(out) if out.size else None, ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return out
+
+    def lhs_combine(self, curve, base: int, partials: np.ndarray, want_carries: bool = True):
+        cid = _curve_id(curve)
+        d = num_digits(cid, base)
+        partials = np.ascontiguousarray(partials, np.uint8)
+        carry = np.zeros(12, np.uint64)
+        carries = np.zeros((d, 12), np.uint64) if want_carries else None
+        self._check(self.lib.lemsm_lhs_combine(cid, base, _ptr(partials), _ptr(carry), _ptr(carries) if want_carries else None))
+        return carry, carries
+
+    def precompute_multiplicities(self, curve, pts_jacobian, base: int) -> np.ndarray:
+        p = _limbs(pts_jacobian, 12)
+        out = np.zeros((p.shape[0], max(base - 1, 0), 12), np.uint64)
+        self._check(self.lib.lemsm_precompute_multiplicities(self.h, _curve_id(curve), _ptr(p), p.shape[0], base, _ptr(out)))
+        return out
+
+    def gen_walk(self, curve, q_affine: np.ndarray, n: int) -> DeviceBuffer:
+        q = np.ascontiguousarray(q_affine, np.uint64).reshape(8)
+        buf = self.alloc(max(n * 64, 16))
+        self._check(self.lib.lemsm_device_gen_walk(self.h, _curve_id(curve), _ptr(q), n, buf.ptr))
+        return buf
+
+    # ---- debug hooks -----------------------------------------------------------------
+    def debug_montmul(self, curve, a, b) -> np.ndarray:
+        a = _limbs(a, 4); b = _limbs(b, 4)
+        out = np.zeros_like(a)
+        self._check(self.lib.lemsm_debug_montmul(self.h, _curve_id(curve), _ptr(a), _ptr(b), _ptr(out), a.shape[0]))
+        return out
+
+    def debug_fieldop(self, curve, op: int, a, b) -> np.ndarray:
+        a = _limbs(a, 4); b = _limbs(b, 4)
+        out = np.zeros_like(a)
+        self._check(self.lib.lemsm_debug_fieldop(self.h, _curve_id(curve), op, _ptr(a), _ptr(b), _ptr(out), a.shape[0]))
+        return out
+
+    def debug_pointop(self, curve, op: int, acc_xyzz, q) -> np.ndarray:
+        acc = _limbs(acc_xyzz, 16)
+        q = _limbs(q, 8 if op == 0 else 16)
+        out = np.zeros_like(acc)
+        self._check(self.lib.lemsm_debug_pointop(self.h, _curve_id(curve), op, _ptr(acc), _ptr(q), _ptr(out), acc.shape[0]))
+        return out
+
+
+def jacobian_to_canonical(curve, jac) -> bytes:
+    jac = np.ascontiguousarray(jac, np.uint64).reshape(12)
+    out = np.zeros(64, np.uint8)
+    rc = _lib.load().lemsm_jacobian_to_canonical(_curve_id(curve), _ptr(jac), _ptr(out))
+    if rc:
+        raise LemsmError(rc, "jacobian_to_canonical")
+    return out.tobytes()
+
+
+# ---- scalar helpers of the reference (pure integer logic, no points) ------------------
+def order(curve) -> int:                                   # src/argument_witness_calc.rs:54-56
+    return ORDER[_curve_id(curve)]
+
+
+def logb_ceil(x: int, base: int) -> int:                   # src/argument_witness_calc.rs:32-40
+    i = 0
+    while x > 0:
+        x //= base
+        i += 1
+    return i
+
+
+def num_digits(curve, base: int) -> int:                   # src/argument_witness_calc.rs:89-91
+    d = ctypes.c_uint32()
+    rc = _lib.load().lemsm_num_digits(_curve_id(curve), base, ctypes.byref(d))
+    if rc:
+        raise BadBase(rc, "bad base")
+    return d.value
+
+
+def id_by_digit(digit: int) -> Optional[int]:              # src/negbase_utils.rs:46-51
+    return None if digit == 0 else digit - 1
+
+
+def digit_by_id(idx: int) -> int:                          # src/negbase_utils.rs:54-56
+    return idx + 1
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---- reference-named entry points --------------------------------------------------------
+def best_multiexp(coeffs, bases, curve="bn254_g1", ctx: Optional[Context] = None) -> np.ndarray:
+    """sum_i coeffs[i]*bases[i]; returns a Jacobian point (12 limbs)."""
+    return (ctx or default_context()).msm(curve, coeffs, bases)
+
+
+def compute_lhs_witness(scalars, pts, base: int, curve="grumpkin", ctx: Optional[Context] = None):
+    """Returns (carry, per_digit_carries): `.0` of the reference's return value and the carries
+    its `ret` vector is built from (each RegularFunction = compute_divisor_witness of a point list
+    ending in -carry_i; that polynomial step stays on the Rust side)."""
+    return (ctx or default_context()).lhs_msm(curve, scalars, pts, base, True)
+
+
+def negbase_decompose(x: int, base: int, ctx: Optional[Context] = None) -> List[int]:
+    """Digits LSB first, no padding, [] for 0 (src/negbase_utils.rs:20-36).  x >= 0 here: the
+    reference's callers only pass non-negative scalars (src/argument_witness_calc.rs:99)."""
+    if x < 0 or x >= 1 << 256:
+        raise ValueError("x must be in [0, 2^256)")
+    if base < 2:
+        raise BadBase(_lib.LEMSM_ERR_BAD_BASE, "base must be >= 2")
+    d = logb_ceil(max(x, 1), base) + 2
+    s = np.frombuffer(int(x).to_bytes(32, "little"), np.uint8).reshape(1, 32)
+    digs = (ctx or default_context()).negbase_decompose_batch(s, base, d)[0].tolist()
+    while digs and digs[-1] == 0:
+        digs.pop()
+    return digs
+
+
+def precompute_multiplicities(pt_jacobian, base: int, curve="grumpkin", ctx: Optional[Context] = None) -> np.ndarray:
+    """[1*P, .., (base-1)*P] as Jacobian points, shape (base-1, 12)."""
+    return (ctx or default_context()).precompute_multiplicities(curve, np.asarray(pt_jacobian).reshape(1, 12), base)[0]

@@ -1,0 +1,1013 @@
+// C ABI implementation (include/lemsm.h): contexts, workspace, launch plans, the kernel
+// pipeline and the host-side tail.  gfx950 only; there is no CPU path.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lemsm.h"
+#include "hostmath.hpp"
+#include "kernels.cuh"
+
+using namespace lemsm;
+
+namespace {
+
+typedef Field32<FqParams> FqDev;   // BN254 G1 coordinates
+typedef Field32<FrParams> FrDev;   // Grumpkin coordinates
+
+// scalar-field orders as 8 x u32 (BN254 G1: r, Grumpkin: p) and isqrt(order)+2
+const u32 ORDER_R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+const u32 ORDER_P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+// isqrt(r)+2 = 0x6f4d8248eeb859fcc6fb4e9fc7b81b1b ; isqrt(p)+2 = 0x6f4d8248eeb859fcc6fb4e9fc7b81b1c
+const u32 BOUND_R[8] = {0xc7b81b1bu, 0xc6fb4e9fu, 0xeeb859fcu, 0x6f4d8248u, 0, 0, 0, 0};
+const u32 BOUND_P[8] = {0xc7b81b1cu, 0xc6fb4e9fu, 0xeeb859fcu, 0x6f4d8248u, 0, 0, 0, 0};
+
+const u32* order_of(int curve) { return curve == LEMSM_BN254_G1 ? ORDER_R : ORDER_P; }
+const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUND_P; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct lemsm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  DevBuf ws;        // workspace arena
+  DevBuf in_s;      // staged scalars (host-pointer entries)
+  DevBuf in_p;      // staged points
+  DevBuf in_aux;    // staged Jacobian points / misc
+  std::string last_error;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0;
+  double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
+  std::map<u64, DevBuf> pyr_cache;   // task tables keyed by (nb, gw)
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+      return LEMSM_ERR_HIP;                                                                 \
+    }                                                                                       \
+  } while (0)
+
+int fail(lemsm_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->last_error = msg;
+  return code;
+}
+
+int reserve(lemsm_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (b.cap >= bytes) return LEMSM_OK;
+  if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + bytes / 8 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { b.p = nullptr; return fail(ctx, LEMSM_ERR_NOMEM, "hipMalloc failed: " + std::string(hipGetErrorString(e))); }
+  b.cap = want;
+  return LEMSM_OK;
+}
+
+// ---- big-integer helpers on 8 x u32 (host) ----
+bool geq8(const u32* a, const u32* b) {
+  for (int i = 7; i >= 0; i--) { if (a[i] > b[i]) return true; if (a[i] < b[i]) return false; }
+  return true;
+}
+void add8(u32* r, const u32* a, const u32* b) {
+  u64 c = 0;
+  for (int i = 0; i < 8; i++) { c += (u64)a[i] + b[i]; r[i] = (u32)c; c >>= 32; }
+}
+u32 logb_ceil8(const u32* x, u32 base) {   // src/argument_witness_calc.rs:32-40
+  u32 m[8]; memcpy(m, x, 32); u32 i = 0;
+  for (;;) {
+    u32 nz = 0; for (int k = 0; k < 8; k++) nz |= m[k];
+    if (!nz) break;
+    u64 rem = 0;
+    for (int k = 7; k >= 0; k--) { u64 cur = (rem << 32) | m[k]; m[k] = (u32)(cur / base); rem = cur % base; }
+    i++;
+  }
+  return i;
+}
+u32 next_pow2(u32 x) { u32 p = 1; while (p < x) p <<= 1; return p; }
+u32 ilog2(u32 x) { u32 l = 0; while ((1u << l) < x) l++; return l; }
+
+// ---- MSM plan (Pippenger, signed windows) ----
+struct MsmPlan {
+  u32 c, W, nb, nbp, L;
+  u32 kadd[8];
+};
+
+// window bits for an n-point MSM: 16 for large n (2-byte windows, 16 windows of 2^15 buckets
+// for 254-bit scalars: divisible by 1/2/4/8 GPUs); fewer for small n so buckets are not mostly empty.
+u32 choose_c(const lemsm_ctx* ctx, size_t n) {
+  if (ctx && ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 16) return (u32)ctx->opt_window_bits;
+  u32 lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
+  int c = (int)lg - 3;
+  if (c < 3) c = 3;
+  if (c > 16) c = 16;
+  return (u32)c;
+}
+
+MsmPlan make_msm_plan(const lemsm_ctx* ctx, int curve, size_t n) {
+  MsmPlan p; memset(&p, 0, sizeof p);
+  p.c = choose_c(ctx, n);
+  p.nb = 1u << (p.c - 1);
+  p.nbp = p.nb; p.L = ilog2(p.nbp);
+  const u32* order = order_of(curve);
+  // smallest W such that (order-1 + K_W) >> (c(W-1)) <= nb, K_W = sum_{w<W-1} 2^(c-1) 2^(cw)
+  for (u32 W = (254 + p.c - 1) / p.c;; W++) {
+    u32 K[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (u32 w = 0; w + 1 < W; w++) {
+      u32 bit = w * p.c + p.c - 1;
+      if (bit < 256) K[bit >> 5] |= 1u << (bit & 31);
+    }
+    u32 s[9]; u64 cy = 0;
+    for (int i = 0; i < 8; i++) { cy += (u64)order[i] + K[i]; s[i] = (u32)cy; cy >>= 32; }
+    s[8] = (u32)cy;
+    // top = s >> (c (W-1))
+    u32 sh = p.c * (W - 1);
+    bool fits = true;
+    if (s[8]) fits = false;   // overflowed 256 bits (cannot happen for 254-bit orders)
+    // compute top window value (may be up to 64 bits wide if W too small)
+    u64 top = 0; bool big = false;
+    for (int bit = 255; bit >= (int)sh; bit--) {
+      u32 b = (s[bit >> 5] >> (bit & 31)) & 1u;
+      if (top >> 62) big = true;
+      top = (top << 1) | b;
+    }
+    if (big || top > p.nb) fits = false;
+    if (sh >= 256) { fits = true; }
+    if (fits) { p.W = W; memcpy(p.kadd, K, 32); break; }
+  }
+  return p;
+}
+
+template <class F> struct FieldTag {};
+
+// ---- pyramid task tables ----
+struct PyrPlan {
+  std::vector<std::vector<PyrTask>> steps;   // steps[s-1] for s = 1..L
+  std::vector<u32> step_max_count;
+  CopyTask copy;                              // U_{L-1} = A^{L-1}[1]
+};
+
+// arena offsets (in points) for one group
+struct ArenaLayout {
+  u32 bucket_off, apyr_off, rbuf_off, out_off, total_points;
+};
+
+ArenaLayout make_arena(u32 NBpad, u32 nbp, u32 gw, u32 L) {
+  ArenaLayout a;
+  a.bucket_off = 0;
+  a.apyr_off = NBpad;
+  a.rbuf_off = a.apyr_off + nbp * gw;
+  a.out_off = a.rbuf_off + nbp * gw;
+  a.total_points = a.out_off + (L + 1) * gw;
+  return a;
+}
+
+PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbp, u32 L) {
+  PyrPlan pp;
+  auto offA = [&](u32 l) { return nbp - (nbp >> (l - 1)); };                    // level l >= 1 inside a window's A region
+  auto offR = [&](u32 l, u32 j) { u32 rs = nbp >> (l + 1); return (nbp - (nbp >> l)) + (rs - (rs >> (j - 1))); };
+  auto srcA = [&](u32 l, PyrTask& t) {    // A^l as a source
+    if (l == 0) { t.src_off = ar.bucket_off; t.src_wstride = nb; t.src_valid = nb; }
+    else { t.src_off = ar.apyr_off + offA(l); t.src_wstride = nbp; t.src_valid = nbp >> l; }
+  };
+  for (u32 s = 1; s <= L; s++) {
+    std::vector<PyrTask> tasks;
+    PyrTask t; memset(&t, 0, sizeof t);
+    srcA(s - 1, t);
+    t.stride = 1; t.phase = 0; t.count = nbp >> s;
+    if (s == L) { t.dst_off = ar.out_off; t.dst_wstride = L + 1; }
+    else { t.dst_off = ar.apyr_off + offA(s); t.dst_wstride = nbp; }
+    tasks.push_back(t);
+    if (s + 1 <= L) {
+      u32 cnt = nbp >> (s + 1);
+      for (u32 l = 0; l < s; l++) {
+        u32 j = s - l;
+        PyrTask r; memset(&r, 0, sizeof r);
+        if (j == 1) { srcA(l, r); r.stride = 2; r.phase = 1; }
+        else { r.src_off = ar.rbuf_off + offR(l, j - 1); r.src_wstride = nbp; r.src_valid = nbp >> (l + j); r.stride = 1; r.phase = 0; }
+        r.count = cnt;
+        if (cnt == 1) { r.dst_off = ar.out_off + 1 + l; r.dst_wstride = L + 1; }
+        else { r.dst_off = ar.rbuf_off + offR(l, j); r.dst_wstride = nbp; }
+        tasks.push_back(r);
+      }
+    }
+    pp.step_max_count.push_back(nbp >> s);
+    pp.steps.push_back(tasks);
+  }
+  // U_{L-1} = A^{L-1}[1]
+  memset(&pp.copy, 0, sizeof pp.copy);
+  if (L == 1) { pp.copy.src_off = ar.bucket_off; pp.copy.src_wstride = nb; pp.copy.src_valid_idx = nb; }
+  else { pp.copy.src_off = ar.apyr_off + offA(L - 1); pp.copy.src_wstride = nbp; pp.copy.src_valid_idx = 2; }
+  pp.copy.src_idx = 1;
+  pp.copy.dst_off = ar.out_off + L; pp.copy.dst_wstride = L + 1;
+  return pp;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Workspace carve for one window group.
+struct GroupWs {
+  char* arena;          // points arena (bucket sums, pyramid, out)
+  u32* bin_total; u32* bin_cursor; u32* bin_start; u32* tile_prefix; u32* meta;
+  u32* bucket_count; u32* bucket_cursor; u32* bucket_start;
+  u32* block_counts;
+  u32* entries; u32* sorted;
+  u32* rec_key_a; char* rec_pt_a; u32* rec_key_b; char* rec_pt_b;
+  PyrTask* tasks; CopyTask* copy_task;
+  size_t zero_begin, zero_bytes;   // contiguous region to memset(0) per group (offset from base)
+  size_t total;
+};
+
+const u32 L2_RECORDS = 8;
+
+GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t ntasks_total) {
+  GroupWs w; size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  u32 NBpad = pl.nbins << pl.LB;
+  // zeroed region first: bin_total, bin_cursor, bucket_count, bucket_cursor, bucket sums
+  size_t z0 = off;
+  size_t o_bin_total = take(MAX_BINS * 4), o_bin_cursor = take(MAX_BINS * 4);
+  size_t o_bcount = take((size_t)NBpad * 4), o_bcursor = take((size_t)NBpad * 4);
+  size_t o_arena = take((size_t)ar.total_points * 128);
+  size_t zend = o_arena + (size_t)NBpad * 128;   // only the bucket sums need zeroing
+  size_t o_bin_start = take((MAX_BINS + 1) * 4), o_tile_prefix = take((MAX_BINS + 1) * 4), o_meta = take(64);
+  size_t o_bstart = take(((size_t)NBpad + 1) * 4);
+  size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 4);
+  size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
+  size_t o_entries = take(Mmax * 4 + 16), o_sorted = take(Mmax * 4 + 16);
+  size_t R1 = 2 * (size_t)pl.nthr1;
+  size_t R2 = 2 * ((R1 + L2_RECORDS - 1) / L2_RECORDS);
+  size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * 128 + 128), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * 128 + 128);
+  size_t o_tasks = take(ntasks_total * sizeof(PyrTask) + 64), o_copy = take(sizeof(CopyTask) + 64);
+  w.total = off;
+  if (base) {
+    w.bin_total = (u32*)(base + o_bin_total); w.bin_cursor = (u32*)(base + o_bin_cursor);
+    w.bucket_count = (u32*)(base + o_bcount); w.bucket_cursor = (u32*)(base + o_bcursor);
+    w.arena = base + o_arena;
+    w.bin_start = (u32*)(base + o_bin_start); w.tile_prefix = (u32*)(base + o_tile_prefix); w.meta = (u32*)(base + o_meta);
+    w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc);
+    w.entries = (u32*)(base + o_entries); w.sorted = (u32*)(base + o_sorted);
+    w.rec_key_a = (u32*)(base + o_rka); w.rec_pt_a = base + o_rpa; w.rec_key_b = (u32*)(base + o_rkb); w.rec_pt_b = base + o_rpb;
+    w.tasks = (PyrTask*)(base + o_tasks); w.copy_task = (CopyTask*)(base + o_copy);
+  }
+  w.zero_begin = z0; w.zero_bytes = zend - z0;
+  return w;
+}
+
+GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32 w0, u32 w1, u32 d) {
+  GroupPlan g; memset(&g, 0, sizeof g);
+  g.n = n; g.c = c; g.nb = nb; g.W = W; g.w0 = w0; g.w1 = w1; g.d = d;
+  g.NB = (w1 - w0) * nb;
+  u32 LB = 0;
+  while (((g.NB + (1u << LB) - 1) >> LB) > MAX_BINS) LB++;
+  g.LB = LB;
+  g.nbins = (g.NB + (1u << LB) - 1) >> LB;
+  if (g.nbins == 0) g.nbins = 1;
+  u32 spb = (n + 1023) / 1024;
+  spb = std::max(256u, std::min(16384u, spb));
+  spb = (spb + 255) / 256 * 256;
+  g.spb = spb;
+  g.nblk1 = (n + spb - 1) / spb;
+  if (g.nblk1 == 0) g.nblk1 = 1;
+  size_t Mmax = (size_t)n * (w1 - w0);
+  u32 T2 = ctx->opt_tile > 0 ? (u32)ctx->opt_tile : 16384u;
+  g.T2 = T2;
+  g.max_tiles = (u32)(Mmax / T2) + g.nbins + 1;
+  u32 L1;
+  if (ctx->opt_chunk > 0) L1 = (u32)ctx->opt_chunk;
+  else {
+    size_t target = (size_t)256 * 4 * 4 * 64;
+    size_t l = Mmax / target;
+    L1 = (u32)std::max((size_t)8, std::min((size_t)256, l));
+  }
+  g.L1 = L1;
+  g.nthr1 = (u32)((Mmax + L1 - 1) / L1);
+  if (g.nthr1 == 0) g.nthr1 = 1;
+  return g;
+}
+
+// max windows per group: NB_group <= MAX_BINS << MAX_LB
+u32 max_group_windows(u32 nb) {
+  u32 cap = (MAX_BINS << MAX_LB) / nb;
+  return cap == 0 ? 1 : cap;
+}
+
+// Runs one window group [w0,w1): sort + accumulate + reduce; results (gw x (L+1) XYZZ points)
+// are left in the arena's out area and copied to d_out (device) + gslot.
+template <class F, class Src>
+int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
+              char* ws_base, char* d_out /* device, gw*(L+1)*128 bytes */, bool time_it) {
+  hipStream_t st = ctx->stream;
+  u32 gw = pl.w1 - pl.w0;
+  u32 NBpad = pl.nbins << pl.LB;
+  ArenaLayout ar = make_arena(NBpad, nbp, gw, L);
+  PyrPlan pp = make_pyr_plan(ar, pl.nb, nbp, L);
+  size_t ntasks_total = 0;
+  for (auto& s : pp.steps) ntasks_total += s.size();
+  GroupWs w = carve(ws_base, pl, ar, ntasks_total);
+
+  HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
+  // upload task tables (small; pageable memcpy is synchronous w.r.t. host, fine)
+  {
+    std::vector<PyrTask> flat;
+    for (auto& s : pp.steps) flat.insert(flat.end(), s.begin(), s.end());
+    HIPCHK(ctx, hipMemcpyAsync(w.tasks, flat.data(), flat.size() * sizeof(PyrTask), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(w.copy_task, &pp.copy, sizeof(CopyTask), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));   // flat/pp are stack objects
+  }
+
+  hipLaunchKernelGGL((k_count1<Src>), dim3(pl.nblk1), dim3(256), 0, st, src, pl, w.block_counts, w.bin_total);
+  hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
+  hipLaunchKernelGGL((k_scatter1<Src>), dim3(pl.nblk1), dim3(256), 0, st, src, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
+  hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.bin_start, w.tile_prefix, w.meta, w.bucket_count);
+  hipLaunchKernelGGL(k_bucketscan, dim3((pl.nbins + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
+  hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.bin_start, w.tile_prefix, w.meta,
+                     w.bucket_start, w.bucket_cursor, w.sorted);
+
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+  hipLaunchKernelGGL((k_accum1<F>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, w.sorted, w.bucket_start, w.meta,
+                     (const uint4*)d_points, w.arena + (size_t)ar.bucket_off * 128, w.rec_key_a, w.rec_pt_a);
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+
+  // edge-record levels
+  {
+    u32 R = 2 * pl.nthr1;
+    u32* ik = w.rec_key_a; char* ip = w.rec_pt_a; u32* ok = w.rec_key_b; char* op = w.rec_pt_b;
+    for (;;) {
+      u32 nthr = (R + L2_RECORDS - 1) / L2_RECORDS;
+      hipLaunchKernelGGL((k_segreduce<F>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, L2_RECORDS, ik, ip,
+                         w.arena + (size_t)ar.bucket_off * 128, ok, op);
+      if (nthr == 1) break;
+      R = 2 * nthr;
+      std::swap(ik, ok); std::swap(ip, op);
+    }
+  }
+  // bucket reduction pyramid
+  {
+    size_t toff = 0;
+    for (u32 s = 1; s <= L; s++) {
+      auto& tasks = pp.steps[s - 1];
+      u32 maxc = pp.step_max_count[s - 1];
+      size_t threads = (size_t)tasks.size() * maxc * gw;
+      hipLaunchKernelGGL((k_pyramid<F>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, w.tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
+      toff += tasks.size();
+    }
+    u32 cthreads = gw * 8;
+    hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, w.copy_task, 1u, gw, w.arena);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(d_out, w.arena + (size_t)ar.out_off * 128, (size_t)gw * (L + 1) * 128, hipMemcpyDeviceToDevice, st));
+  return LEMSM_OK;
+}
+
+size_t group_ws_bytes(const GroupPlan& pl, u32 nbp, u32 L) {
+  u32 gw = pl.w1 - pl.w0;
+  ArenaLayout ar = make_arena(pl.nbins << pl.LB, nbp, gw, L);
+  size_t ntasks = (size_t)(L + 2) * (L + 2);
+  GroupWs w = carve(nullptr, pl, ar, ntasks);
+  return w.total + 4096;
+}
+
+// Generic windowed bucket pipeline over window range [wb,we): fills host_out with
+// (we-wb) x (L+1) XYZZ points, summed over slabs.
+template <class P64, class F, class MakeSrc>
+int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 wb, u32 we, u32 d,
+                const void* d_points, std::vector<host::pt>& host_out) {
+  typedef host::HG<P64> G;
+  u32 nw = we - wb;
+  host_out.assign((size_t)nw * (L + 1), G::identity());
+  if (n == 0 || nw == 0) return LEMSM_OK;
+  hipStream_t st = ctx->stream;
+  const size_t SLAB = (size_t)1 << MAX_SLAB_LOG;
+  u32 gmax = max_group_windows(nb);
+  // workspace sizing over all (slab, group) combinations
+  size_t need = 0;
+  for (size_t s0 = 0; s0 < n; s0 += SLAB) {
+    u32 sn = (u32)std::min(SLAB, n - s0);
+    for (u32 g0 = wb; g0 < we; g0 += gmax) {
+      GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, g0, std::min(we, g0 + gmax), d);
+      need = std::max(need, group_ws_bytes(pl, nbp, L));
+    }
+  }
+  size_t out_bytes = (size_t)nw * (L + 1) * 128;
+  int rc = reserve(ctx, ctx->ws, need + out_bytes + 4096);
+  if (rc) return rc;
+  char* ws_base = (char*)ctx->ws.p;
+  char* d_out = ws_base + align_up(need, 256);
+  std::vector<host::pt> tmp((size_t)nw * (L + 1));
+  HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+  ctx->t_accum_ms = 0; ctx->n_accum = 0;
+  for (size_t s0 = 0; s0 < n; s0 += SLAB) {
+    u32 sn = (u32)std::min(SLAB, n - s0);
+    for (u32 g0 = wb; g0 < we; g0 += gmax) {
+      u32 g1 = std::min(we, g0 + gmax);
+      GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, g0, g1, d);
+      auto src = make_src(s0, sn);
+      rc = run_group<F>(ctx, src, pl, nbp, L, (const char*)d_points + s0 * 64, ws_base,
+                        d_out + (size_t)(g0 - wb) * (L + 1) * 128, true);
+      if (rc) return rc;
+      HIPCHK(ctx, hipStreamSynchronize(st));
+      float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+      ctx->t_accum_ms += ms; ctx->n_accum++;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(tmp.data(), d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (s0 == 0) host_out = tmp;
+    else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = G::add(host_out[i], tmp[i]);
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+  float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+  ctx->t_total_ms = ms;
+  return LEMSM_OK;
+}
+
+// S_w = total + sum_l 2^l U_l  for one window record [total, U_0..U_{L-1}]
+template <class P64>
+host::pt window_sum(const host::pt* rec, u32 L) {
+  typedef host::HG<P64> G;
+  host::pt acc = G::identity();
+  for (int l = (int)L - 1; l >= 0; l--) { acc = G::dbl(acc); acc = G::add(acc, rec[1 + l]); }
+  return G::add(acc, rec[0]);
+}
+
+template <class P64>
+void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W x (L+1) */, u64 out[12]) {
+  typedef host::HG<P64> G;
+  host::pt acc = G::identity();
+  for (int w = (int)mp.W - 1; w >= 0; w--) {
+    for (u32 k = 0; k < mp.c; k++) acc = G::dbl(acc);
+    acc = G::add(acc, window_sum<P64>(recs + (size_t)w * (mp.L + 1), mp.L));
+  }
+  G::to_jacobian(acc, out);
+}
+
+template <class P64, class F>
+int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, u32 wb, u32 we,
+                  std::vector<host::pt>& out) {
+  MsmPlan mp = make_msm_plan(ctx, curve, n);
+  if (wb > we || we > mp.W) return fail(ctx, LEMSM_ERR_BAD_ARG, "window range out of bounds");
+  auto make_src = [&](size_t s0, u32) {
+    PipSrc s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
+    memcpy(s.kadd, mp.kadd, 32); return s;
+  };
+  return run_windows<P64, F>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, out);
+}
+
+int check_curve(lemsm_ctx* ctx, int curve) {
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return fail(ctx, LEMSM_ERR_BAD_CURVE, "unknown curve id");
+  return LEMSM_OK;
+}
+
+int stage(lemsm_ctx* ctx, DevBuf& b, const void* host, size_t bytes) {
+  int rc = reserve(ctx, b, bytes ? bytes : 16);
+  if (rc) return rc;
+  if (bytes) HIPCHK(ctx, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return LEMSM_OK;
+}
+
+// ---- lhs (negabase) plan ----
+struct LhsPlan { u32 base, d, nb, nbp, L; };
+int make_lhs_plan(int curve, u32 base, LhsPlan& lp) {
+  if (base < 3) return LEMSM_ERR_BAD_BASE;
+  lp.base = base; lp.d = logb_ceil8(bound_of(curve), base) + 1;
+  lp.nb = base - 1; lp.nbp = next_pow2(lp.nb); if (lp.nbp < 2) lp.nbp = 2;
+  lp.L = ilog2(lp.nbp);
+  return LEMSM_OK;
+}
+
+// digits (position-major, d x n) for the lhs path; leaves err words in ctx workspace tail
+struct LhsDigits { uint8_t* digitsT; u32* err; };
+
+int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const LhsPlan& lp, DevBuf& buf, LhsDigits& out) {
+  size_t bytes = align_up((size_t)lp.d * n, 256) + 256 + 64;
+  int rc = reserve(ctx, buf, bytes);
+  if (rc) return rc;
+  char* base = (char*)buf.p;
+  out.digitsT = (uint8_t*)base;
+  u32* bound_d = (u32*)(base + align_up((size_t)lp.d * n, 256));
+  out.err = bound_d + 8;
+  u32 init[12];
+  memcpy(init, bound_of(curve), 32); init[8] = 0xffffffffu; init[9] = 0; init[10] = 0; init[11] = 0;
+  HIPCHK(ctx, hipMemcpyAsync(bound_d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (n) hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)d_scalars, (u32)n,
+                            lp.base, lp.d, bound_d, 1, (uint8_t*)nullptr, out.digitsT, out.err);
+  HIPCHK(ctx, hipGetLastError());
+  return LEMSM_OK;
+}
+
+template <class P64, class F>
+int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, const LhsPlan& lp,
+                  u32 pb, u32 pe, std::vector<host::pt>& out, size_t* bad_index) {
+  if (pb > pe || pe > lp.d) return fail(ctx, LEMSM_ERR_BAD_ARG, "position range out of bounds");
+  if (n >= ((size_t)1 << 32)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  LhsDigits dg;
+  int rc = lhs_digits(ctx, curve, d_scalars, n, lp, ctx->in_aux, dg);
+  if (rc) return rc;
+  // the digit matrix is position-major over the whole n; slabs index it with an offset
+  auto make_src = [&](size_t s0, u32) { NegSrc s; s.digitsT = dg.digitsT + s0; return s; };
+  // NegSrc indexes digitsT[w * pl.n + j] with pl.n = slab size, so multi-slab inputs need the
+  // full row stride: restrict the lhs path to one slab (n <= 2^24) for now.
+  if (n > ((size_t)1 << MAX_SLAB_LOG)) return fail(ctx, LEMSM_ERR_BAD_ARG, "lhs path supports n <= 2^24 per call");
+  rc = run_windows<P64, F>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, out);
+  if (rc) return rc;
+  u32 err[2] = {0xffffffffu, 0};
+  if (n) {
+    HIPCHK(ctx, hipMemcpyAsync(err, dg.err, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (err[0] != 0xffffffffu) {
+    if (bad_index) *bad_index = err[0];
+    return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar out of range (>= isqrt(order)+2)");
+  }
+  return LEMSM_OK;
+}
+
+// carries: MSB-first Horner with multiplier -base over per-position sums (src/argument_witness_calc.rs:105-127)
+template <class P64>
+void lhs_combine_t(const LhsPlan& lp, const host::pt* recs /* d x (L+1), position (LSB-first) major */, u64 out_carry[12],
+                   u64* out_carries) {
+  typedef host::HG<P64> G;
+  host::pt carry = G::identity();
+  for (u32 it = 0; it < lp.d; it++) {
+    u32 pos = lp.d - 1 - it;
+    carry = G::mul_small(G::neg(carry), lp.base);                                  // :118
+    carry = G::add(carry, window_sum<P64>(recs + (size_t)pos * (lp.L + 1), lp.L)); // :120-125
+    if (out_carries) G::to_jacobian(carry, out_carries + 12 * (size_t)it);
+  }
+  G::to_jacobian(carry, out_carry);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_precompute_mult(const uint4* __restrict__ jac, u32 n, u32 base, uint4* __restrict__ out) {
+  typedef XYZZ<F> G; typedef typename F::fe fe;
+  u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  fe X, Y, Z; F::load(X, jac + (size_t)j * 6); F::load(Y, jac + (size_t)j * 6 + 2); F::load(Z, jac + (size_t)j * 6 + 4);
+  typename G::pt p;
+  if (F::is_zero(Z)) G::set_identity(p);
+  else { p.x = X; p.y = Y; F::sqr(p.zz, Z); F::mul(p.zzz, p.zz, Z); }
+  typename G::pt acc = p;
+  for (u32 k = 1; k < base; k++) {
+    uint4* o = out + ((size_t)j * (base - 1) + (k - 1)) * 6;
+    if (G::is_identity(acc)) { uint4 z = make_uint4(0, 0, 0, 0); for (int q = 0; q < 6; q++) o[q] = z; }
+    else {
+      fe t, xo, yo;
+      F::sqr(t, acc.zz); F::mul(xo, acc.x, t);
+      F::sqr(t, acc.zzz); F::mul(yo, acc.y, t);
+      F::store(o, xo); F::store(o + 2, yo); F::store(o + 4, acc.zzz);
+    }
+    G::add(acc, p);
+  }
+}
+
+// P_i = (i+1) Q, thread t owns [t*KB, (t+1)*KB); affine output through a per-thread batch inversion.
+template <class F, int KB>
+__global__ __launch_bounds__(256) void k_gen_walk(const uint4* __restrict__ q_aff, u32 n, uint4* __restrict__ out, char* __restrict__ scratch) {
+  typedef XYZZ<F> G; typedef typename F::fe fe;
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  const u32 nthreads = gridDim.x * 256;
+  const u64 j0 = (u64)t * KB;
+  if (j0 >= n) return;
+  const u32 cnt = (u32)min((u64)KB, (u64)n - j0);
+  fe qx, qy; F::load(qx, q_aff); F::load(qy, q_aff + 2);
+  // acc = (j0 + 1) * Q
+  typename G::pt acc; G::set_identity(acc);
+  u32 k = (u32)j0 + 1;
+  for (int b = 31; b >= 0; b--) {
+    if (!G::is_identity(acc)) { typename G::pt tmp = acc; G::dbl(acc, tmp); }
+    if ((k >> b) & 1u) G::madd(acc, qx, qy);
+  }
+  fe pref; F::set_one(pref);
+  for (u32 i = 0; i < cnt; i++) {
+    if (i) G::madd(acc, qx, qy);
+    char* s = scratch + ((size_t)i * nthreads + t) * 160;
+    G::store(s, acc); F::store(s + 128, pref);
+    F::mul(pref, pref, acc.zzz);     // walk points are never the identity for n < group order
+  }
+  fe inv; F::inv(inv, pref);
+  for (u32 i = cnt; i-- > 0;) {
+    const char* s = scratch + ((size_t)i * nthreads + t) * 160;
+    typename G::pt p; G::load(p, s); fe pr; F::load(pr, s + 128);
+    fe izzz, izz, x, y;
+    F::mul(izzz, inv, pr);
+    F::mul(inv, inv, p.zzz);
+    F::mul(izz, izzz, p.zz); F::sqr(izz, izz);
+    F::mul(x, p.x, izz); F::mul(y, p.y, izzz);
+    F::store(out + (j0 + i) * 4, x); F::store(out + (j0 + i) * 4 + 2, y);
+  }
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* lemsm_strerror(int s) {
+  switch (s) {
+    case LEMSM_OK: return "ok";
+    case LEMSM_ERR_LEN_MISMATCH: return "incompatible amount of coefficients";
+    case LEMSM_ERR_SCALAR_OUT_OF_RANGE: return "scalar out of range";
+    case LEMSM_ERR_BAD_BASE: return "base must be in 3..=255";
+    case LEMSM_ERR_BAD_CURVE: return "unknown curve";
+    case LEMSM_ERR_HIP: return "HIP runtime error";
+    case LEMSM_ERR_BAD_ARG: return "bad argument";
+    case LEMSM_ERR_NOMEM: return "out of device memory";
+    case LEMSM_ERR_TOO_MANY_DIGITS: return "too many digits";
+    default: return "unknown status";
+  }
+}
+
+int lemsm_create(int device, lemsm_ctx** out) {
+  if (!out) return LEMSM_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0 || device < 0 || device >= count) return LEMSM_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LEMSM_ERR_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return LEMSM_ERR_HIP;   // kernels are built for gfx950 only
+  if (hipSetDevice(device) != hipSuccess) return LEMSM_ERR_HIP;
+  lemsm_ctx* c = new lemsm_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
+  for (int i = 0; i < 4; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
+  *out = c;
+  return LEMSM_OK;
+}
+
+void lemsm_destroy(lemsm_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux}) if (b->p) (void)hipFree(b->p);
+  for (auto& kv : ctx->pyr_cache) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* lemsm_last_error(const lemsm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
+  if (!ctx || !name) return LEMSM_ERR_BAD_ARG;
+  if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return LEMSM_ERR_BAD_ARG; ctx->opt_window_bits = value; }
+  else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
+  else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
+  else return LEMSM_ERR_BAD_ARG;
+  return LEMSM_OK;
+}
+
+int lemsm_last_timing(const lemsm_ctx* ctx, double out[3]) {
+  if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
+  out[0] = ctx->t_total_ms; out[1] = ctx->t_accum_ms; out[2] = ctx->n_accum;
+  return LEMSM_OK;
+}
+
+int lemsm_msm_plan(const lemsm_ctx* ctx, int curve, size_t n, uint32_t* num_windows, size_t* partial_bytes_per_window) {
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
+  MsmPlan mp = make_msm_plan(ctx, curve, n);
+  if (num_windows) *num_windows = mp.W;
+  if (partial_bytes_per_window) *partial_bytes_per_window = (size_t)(mp.L + 1) * 128;
+  return LEMSM_OK;
+}
+
+int lemsm_msm_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n,
+                             uint32_t win_begin, uint32_t win_end, uint8_t* out_partials) {
+  if (!ctx || !out_partials) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<host::pt> out;
+  if (curve == LEMSM_BN254_G1) rc = msm_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, win_begin, win_end, out);
+  else rc = msm_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, win_begin, win_end, out);
+  if (rc) return rc;
+  memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
+  return LEMSM_OK;
+}
+
+int lemsm_msm_combine(const lemsm_ctx* ctx, int curve, size_t n, const uint8_t* partials, uint64_t out[12]) {
+  if (!partials || !out) return LEMSM_ERR_BAD_ARG;
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
+  MsmPlan mp = make_msm_plan(ctx, curve, n);
+  std::vector<host::pt> recs((size_t)mp.W * (mp.L + 1));
+  memcpy(recs.data(), partials, recs.size() * sizeof(host::pt));
+  if (curve == LEMSM_BN254_G1) msm_combine_t<host::FqParams64>(mp, recs.data(), out);
+  else msm_combine_t<host::FrParams64>(mp, recs.data(), out);
+  return LEMSM_OK;
+}
+
+int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, uint64_t out[12]) {
+  if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (n == 0) { memset(out, 0, 96); return LEMSM_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  MsmPlan mp = make_msm_plan(ctx, curve, n);
+  std::vector<host::pt> recs;
+  if (curve == LEMSM_BN254_G1) {
+    rc = msm_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, 0, mp.W, recs);
+    if (rc) return rc;
+    msm_combine_t<host::FqParams64>(mp, recs.data(), out);
+  } else {
+    rc = msm_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, 0, mp.W, recs);
+    if (rc) return rc;
+    msm_combine_t<host::FrParams64>(mp, recs.data(), out);
+  }
+  return LEMSM_OK;
+}
+
+int lemsm_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* points, size_t n, uint64_t out[12]) {
+  if (!ctx || !out || (n && (!scalars || !points))) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (n == 0) { memset(out, 0, 96); return LEMSM_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  rc = stage(ctx, ctx->in_s, scalars, n * 32); if (rc) return rc;
+  rc = stage(ctx, ctx->in_p, points, n * 64); if (rc) return rc;
+  return lemsm_msm_device(ctx, curve, ctx->in_s.p, ctx->in_p.p, n, out);
+}
+int lemsm_msm_bn254_g1(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, size_t n, uint64_t out[12]) { return lemsm_msm(ctx, LEMSM_BN254_G1, s, p, n, out); }
+int lemsm_msm_grumpkin(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, size_t n, uint64_t out[12]) { return lemsm_msm(ctx, LEMSM_GRUMPKIN, s, p, n, out); }
+
+int lemsm_num_digits(int curve, uint8_t base, uint32_t* d) {
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
+  if (base < 2 || !d) return LEMSM_ERR_BAD_BASE;
+  *d = logb_ceil8(bound_of(curve), base) + 1;
+  return LEMSM_OK;
+}
+
+int lemsm_negbase_decompose_batch(lemsm_ctx* ctx, const uint8_t* scalars, size_t n, uint8_t base, uint32_t d, uint8_t* digits) {
+  if (!ctx || (n && (!scalars || !digits))) return LEMSM_ERR_BAD_ARG;
+  if (base < 2) return fail(ctx, LEMSM_ERR_BAD_BASE, "base must be >= 2");
+  if (n == 0 || d == 0) return LEMSM_OK;
+  if (n >= ((size_t)1 << 32)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = stage(ctx, ctx->in_s, scalars, n * 32); if (rc) return rc;
+  size_t dig_bytes = align_up((size_t)n * d, 256);
+  rc = reserve(ctx, ctx->in_aux, dig_bytes + 256); if (rc) return rc;
+  char* b = (char*)ctx->in_aux.p;
+  u32 init[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0xffffffffu, 0, 0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(b + dig_bytes, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)ctx->in_s.p, (u32)n,
+                     (u32)base, d, (const u32*)(b + dig_bytes), 0, (uint8_t*)b, (uint8_t*)nullptr, (u32*)(b + dig_bytes) + 8);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(digits, b, (size_t)n * d, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LEMSM_OK;
+}
+
+int lemsm_lhs_plan(int curve, uint8_t base, uint32_t* num_positions, size_t* partial_bytes) {
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
+  LhsPlan lp; int rc = make_lhs_plan(curve, base, lp); if (rc) return rc;
+  if (num_positions) *num_positions = lp.d;
+  if (partial_bytes) *partial_bytes = (size_t)(lp.L + 1) * 128;
+  return LEMSM_OK;
+}
+
+int lemsm_lhs_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, uint8_t base,
+                             uint32_t pos_begin, uint32_t pos_end, uint8_t* out_partials, size_t* bad_index) {
+  if (!ctx || !out_partials) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<host::pt> out;
+  if (curve == LEMSM_BN254_G1) rc = lhs_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, lp, pos_begin, pos_end, out, bad_index);
+  else rc = lhs_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, lp, pos_begin, pos_end, out, bad_index);
+  if (rc) return rc;
+  memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
+  return LEMSM_OK;
+}
+
+int lemsm_lhs_combine(int curve, uint8_t base, const uint8_t* partials, uint64_t out_carry[12], uint64_t* out_carries) {
+  if (!partials || !out_carry) return LEMSM_ERR_BAD_ARG;
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
+  LhsPlan lp; int rc = make_lhs_plan(curve, base, lp); if (rc) return rc;
+  std::vector<host::pt> recs((size_t)lp.d * (lp.L + 1));
+  memcpy(recs.data(), partials, recs.size() * sizeof(host::pt));
+  if (curve == LEMSM_BN254_G1) lhs_combine_t<host::FqParams64>(lp, recs.data(), out_carry, out_carries);
+  else lhs_combine_t<host::FrParams64>(lp, recs.data(), out_carry, out_carries);
+  return LEMSM_OK;
+}
+
+int lemsm_lhs_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, uint8_t base,
+                         uint64_t out_carry[12], uint64_t* out_carries, size_t* bad_index) {
+  if (!ctx || !out_carry) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<host::pt> recs;
+  if (curve == LEMSM_BN254_G1) {
+    rc = lhs_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, lp, 0, lp.d, recs, bad_index);
+    if (rc) return rc;
+    lhs_combine_t<host::FqParams64>(lp, recs.data(), out_carry, out_carries);
+  } else {
+    rc = lhs_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, lp, 0, lp.d, recs, bad_index);
+    if (rc) return rc;
+    lhs_combine_t<host::FrParams64>(lp, recs.data(), out_carry, out_carries);
+  }
+  return LEMSM_OK;
+}
+
+int lemsm_lhs_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* pts_jac, size_t n, uint8_t base,
+                  uint64_t out_carry[12], uint64_t* out_carries, size_t* bad_index) {
+  if (!ctx || !out_carry || (n && (!scalars || !pts_jac))) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (base < 3) return fail(ctx, LEMSM_ERR_BAD_BASE, "base must be in 3..=255");
+  if (n >= ((size_t)1 << 32)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  rc = stage(ctx, ctx->in_s, scalars, n * 32); if (rc) return rc;
+  // Jacobian -> affine on the device (workspace holds the staged Jacobian points + scratch)
+  const int KB = 32;
+  size_t nthreads = ((n + KB - 1) / KB + 255) / 256 * 256;
+  size_t jac_bytes = align_up(n * 96, 256), scr_bytes = (size_t)KB * nthreads * 32;
+  rc = reserve(ctx, ctx->ws, jac_bytes + scr_bytes + 256); if (rc) return rc;
+  rc = reserve(ctx, ctx->in_p, n ? n * 64 : 16); if (rc) return rc;
+  if (n) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws.p, pts_jac, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    if (curve == LEMSM_BN254_G1)
+      hipLaunchKernelGGL((k_jac_to_affine<FqDev, KB>), dim3((u32)(nthreads / 256)), dim3(256), 0, ctx->stream, (const uint4*)ctx->ws.p, (u32)n,
+                         (uint4*)ctx->in_p.p, (char*)ctx->ws.p + jac_bytes);
+    else
+      hipLaunchKernelGGL((k_jac_to_affine<FrDev, KB>), dim3((u32)(nthreads / 256)), dim3(256), 0, ctx->stream, (const uint4*)ctx->ws.p, (u32)n,
+                         (uint4*)ctx->in_p.p, (char*)ctx->ws.p + jac_bytes);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the workspace is re-carved by the MSM below
+  }
+  return lemsm_lhs_msm_device(ctx, curve, ctx->in_s.p, ctx->in_p.p, n, base, out_carry, out_carries, bad_index);
+}
+int lemsm_lhs_msm_grumpkin(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, size_t n, uint8_t base, uint64_t oc[12], uint64_t* ocs, size_t* bad) {
+  return lemsm_lhs_msm(ctx, LEMSM_GRUMPKIN, s, p, n, base, oc, ocs, bad);
+}
+int lemsm_lhs_msm_bn254_g1(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, size_t n, uint8_t base, uint64_t oc[12], uint64_t* ocs, size_t* bad) {
+  return lemsm_lhs_msm(ctx, LEMSM_BN254_G1, s, p, n, base, oc, ocs, bad);
+}
+
+int lemsm_precompute_multiplicities(lemsm_ctx* ctx, int curve, const uint64_t* pts_jac, size_t n, uint8_t base, uint64_t* out) {
+  if (!ctx || (n && (!pts_jac || !out))) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (base < 2) return fail(ctx, LEMSM_ERR_BAD_BASE, "base must be >= 2");
+  if (n == 0 || base == 1) return LEMSM_OK;
+  if (n >= ((size_t)1 << 31)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t in_bytes = align_up(n * 96, 256), out_bytes = n * (size_t)(base - 1) * 96;
+  rc = reserve(ctx, ctx->ws, in_bytes + out_bytes + 256); if (rc) return rc;
+  char* b = (char*)ctx->ws.p;
+  HIPCHK(ctx, hipMemcpyAsync(b, pts_jac, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  if (curve == LEMSM_BN254_G1)
+    hipLaunchKernelGGL((k_precompute_mult<FqDev>), dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)b, (u32)n, (u32)base, (uint4*)(b + in_bytes));
+  else
+    hipLaunchKernelGGL((k_precompute_mult<FrDev>), dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)b, (u32)n, (u32)base, (uint4*)(b + in_bytes));
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, b + in_bytes, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LEMSM_OK;
+}
+
+int lemsm_jacobian_to_canonical(int curve, const uint64_t jac[12], uint8_t out[64]) {
+  if (!jac || !out) return LEMSM_ERR_BAD_ARG;
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
+  u64 aff[8];
+  host::fe one_plain = {{1, 0, 0, 0}};
+  if (curve == LEMSM_BN254_G1) {
+    typedef host::HG<host::FqParams64> G; typedef host::HF<host::FqParams64> F;
+    host::pt p = G::from_jacobian(jac); G::to_affine(p, aff);
+    if (G::is_identity(p)) { memset(out, 0, 64); return LEMSM_OK; }
+    host::fe x, y; memcpy(x.l, aff, 32); memcpy(y.l, aff + 4, 32);
+    x = F::mul(x, one_plain); y = F::mul(y, one_plain);
+    memcpy(out, x.l, 32); memcpy(out + 32, y.l, 32);
+  } else {
+    typedef host::HG<host::FrParams64> G; typedef host::HF<host::FrParams64> F;
+    host::pt p = G::from_jacobian(jac); G::to_affine(p, aff);
+    if (G::is_identity(p)) { memset(out, 0, 64); return LEMSM_OK; }
+    host::fe x, y; memcpy(x.l, aff, 32); memcpy(y.l, aff + 4, 32);
+    x = F::mul(x, one_plain); y = F::mul(y, one_plain);
+    memcpy(out, x.l, 32); memcpy(out + 32, y.l, 32);
+  }
+  return LEMSM_OK;
+}
+
+int lemsm_device_alloc(lemsm_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+  if (e != hipSuccess) return fail(ctx, LEMSM_ERR_NOMEM, hipGetErrorString(e));
+  return LEMSM_OK;
+}
+int lemsm_device_free(lemsm_ctx* ctx, void* p) {
+  if (!ctx) return LEMSM_ERR_BAD_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipFree(p));
+  return LEMSM_OK;
+}
+int lemsm_device_upload(lemsm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return LEMSM_ERR_BAD_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return LEMSM_OK;
+}
+int lemsm_device_download(lemsm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return LEMSM_ERR_BAD_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return LEMSM_OK;
+}
+
+int lemsm_device_gen_walk(lemsm_ctx* ctx, int curve, const uint64_t q_affine[8], size_t n, void* d_out) {
+  if (!ctx || !q_affine || (n && !d_out)) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (n == 0) return LEMSM_OK;
+  if (n >= ((size_t)1 << 31)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int KB = 32;
+  size_t nthreads = ((n + KB - 1) / KB + 255) / 256 * 256;
+  size_t scr = (size_t)KB * nthreads * 160;
+  rc = reserve(ctx, ctx->ws, scr + 512); if (rc) return rc;
+  char* b = (char*)ctx->ws.p;
+  HIPCHK(ctx, hipMemcpyAsync(b, q_affine, 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (curve == LEMSM_BN254_G1)
+    hipLaunchKernelGGL((k_gen_walk<FqDev, KB>), dim3((u32)(nthreads / 256)), dim3(256), 0, ctx->stream, (const uint4*)b, (u32)n, (uint4*)d_out, b + 256);
+  else
+    hipLaunchKernelGGL((k_gen_walk<FrDev, KB>), dim3((u32)(nthreads / 256)), dim3(256), 0, ctx->stream, (const uint4*)b, (u32)n, (uint4*)d_out, b + 256);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LEMSM_OK;
+}
+
+// ---- debug hooks ----
+static int dbg_run3(lemsm_ctx* ctx, const void* a, size_t abytes, const void* b, size_t bbytes, size_t obytes, char** da, char** db, char** dout) {
+  size_t oa = 0, ob = align_up(abytes, 256), oo = ob + align_up(bbytes, 256);
+  int rc = reserve(ctx, ctx->ws, oo + obytes + 256); if (rc) return rc;
+  char* base = (char*)ctx->ws.p;
+  *da = base + oa; *db = base + ob; *dout = base + oo;
+  if (abytes) HIPCHK(ctx, hipMemcpyAsync(*da, a, abytes, hipMemcpyHostToDevice, ctx->stream));
+  if (bbytes) HIPCHK(ctx, hipMemcpyAsync(*db, b, bbytes, hipMemcpyHostToDevice, ctx->stream));
+  return LEMSM_OK;
+}
+
+int lemsm_debug_montmul(lemsm_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!ctx || !a || !b || !out) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (!n) return LEMSM_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  char *da, *db, *dout;
+  rc = dbg_run3(ctx, a, n * 32, b, n * 32, n * 32, &da, &db, &dout); if (rc) return rc;
+  dim3 g((u32)((n + 255) / 256)), blk(256);
+  if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_montmul<FqDev>), g, blk, 0, ctx->stream, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  else hipLaunchKernelGGL((k_dbg_montmul<FrDev>), g, blk, 0, ctx->stream, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LEMSM_OK;
+}
+
+int lemsm_debug_fieldop(lemsm_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!ctx || !a || !b || !out) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (!n) return LEMSM_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  char *da, *db, *dout;
+  rc = dbg_run3(ctx, a, n * 32, b, n * 32, n * 32, &da, &db, &dout); if (rc) return rc;
+  dim3 g((u32)((n + 255) / 256)), blk(256);
+  if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_fieldop<FqDev>), g, blk, 0, ctx->stream, op, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  else hipLaunchKernelGGL((k_dbg_fieldop<FrDev>), g, blk, 0, ctx->stream, op, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LEMSM_OK;
+}
+
+int lemsm_debug_pointop(lemsm_ctx* ctx, int curve, int op, const uint64_t* acc, const uint64_t* q, uint64_t* out, size_t n) {
+  if (!ctx || !acc || !q || !out) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (!n) return LEMSM_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t qb = op == 0 ? 64 : 128;
+  char *da, *db, *dout;
+  rc = dbg_run3(ctx, acc, n * 128, q, n * qb, n * 128, &da, &db, &dout); if (rc) return rc;
+  dim3 g((u32)((n + 63) / 64)), blk(64);
+  if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_pointop<FqDev>), g, blk, 0, ctx->stream, op, da, db, dout, (u32)n);
+  else hipLaunchKernelGGL((k_dbg_pointop<FrDev>), g, blk, 0, ctx->stream, op, da, db, dout, (u32)n);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 128, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LEMSM_OK;
+}
+
+}  // extern "C"

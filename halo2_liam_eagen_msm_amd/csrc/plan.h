@@ -1,0 +1,35 @@
+// Launch plan shared by host code and kernels (plain C structs, passed by value).
+#pragma once
+#include <stdint.h>
+
+namespace lemsm {
+
+// Maximum coarse bins per pass-1 launch (LDS histogram: 2 x 4096 x 4 B = 32 KiB).
+static const uint32_t MAX_BINS = 4096;
+// Local (within-bin) bucket bits carried in a pass-1 entry.
+static const uint32_t MAX_LB = 7;
+// Points per slab: a pass-1 entry packs idx(24) | local(7) | sign(1).
+static const uint32_t MAX_SLAB_LOG = 24;
+
+// One "window group": the windows [w0,w1) of one MSM that are sorted and
+// accumulated together.  "Window" is a Pippenger window for the full-width
+// path and a negabase digit position for the lhs path.
+struct GroupPlan {
+  uint32_t n;        // points in this slab
+  uint32_t c;        // window bits (Pippenger path; 0 on the negabase path)
+  uint32_t nb;       // buckets per window: 2^(c-1) or B-1
+  uint32_t w0, w1;   // windows of this group
+  uint32_t W;        // total windows of the MSM (top window is unsigned)
+  uint32_t NB;       // (w1-w0)*nb  buckets in this group
+  uint32_t LB;       // local bucket bits
+  uint32_t nbins;    // ceil(NB / 2^LB) <= MAX_BINS
+  uint32_t spb;      // scalars per pass-1 block
+  uint32_t nblk1;    // pass-1 blocks = ceil(n / spb)
+  uint32_t T2;       // entries per pass-2 tile
+  uint32_t max_tiles;// upper bound on pass-2 tiles
+  uint32_t L1;       // entries per thread in the accumulate kernel
+  uint32_t nthr1;    // upper bound on accumulate threads = ceil(n*(w1-w0) / L1)
+  uint32_t d;        // negabase: digits per scalar (row stride of the digit matrix)
+};
+
+}  // namespace lemsm

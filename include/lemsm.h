@@ -1,0 +1,163 @@
+/*
+ * lemsm -- MI355X (gfx950) MSM witness path for Liam Eagen's MSM argument.
+ *
+ * C ABI that the reference crate's Rust code would bind (see INTEGRATION.md for the
+ * Rust `extern "C"` block and the shim that keeps the reference's entry signatures).
+ * The reference has no FFI today; each entry below names the Rust function it stands
+ * behind (paths relative to the reference repository root):
+ *
+ *   lemsm_msm_*                  halo2::arithmetic::best_multiexp(coeffs, bases)
+ *                                (third-party; imported src/argument_witness_calc.rs:20,
+ *                                called :144 and src/regular_functions_utils.rs:655,679,694,726)
+ *   lemsm_lhs_msm_*              compute_lhs_witness MSM core, src/argument_witness_calc.rs:87-127,132-134
+ *                                (the per-digit divisor witnesses of :129 stay in Rust; they are
+ *                                built from the per-digit carries returned here)
+ *   lemsm_negbase_decompose_batch negbase_decompose, src/negbase_utils.rs:20-36, over a slice
+ *   lemsm_num_digits             d = logb_ceil(isqrt(order)+2, base)+1, src/argument_witness_calc.rs:89-91
+ *   lemsm_precompute_multiplicities precompute_multiplicities, src/argument_witness_calc.rs:43-51
+ *
+ * Conventions
+ *   scalars   n x 32 bytes, canonical little-endian integers < scalar-field order
+ *             (== PrimeField::to_repr(), what best_multiexp and compute_lhs_witness read:
+ *             src/argument_witness_calc.rs:93)
+ *   field elt 4 x uint64 little-endian limbs in Montgomery form, R = 2^256
+ *             (== SerdeObject::to_raw_bytes(), src/scripts.rs:44, src/precomputed_fft_data.rs:72)
+ *   affine    (x[4], y[4]); the identity is (0,0)
+ *   jacobian  (x[4], y[4], z[4]), x_aff = X/Z^2, y_aff = Y/Z^3; the identity has z == 0.
+ *             Outputs are valid Jacobian points but their coordinates are NOT canonical
+ *             (they depend on summation order); compare as group elements or through
+ *             lemsm_jacobian_to_canonical.
+ *   curves    LEMSM_BN254_G1: y^2 = x^3 + 3 over p, scalars mod r
+ *             LEMSM_GRUMPKIN:  y^2 = x^3 - 17 over r, scalars mod p
+ *
+ * Ownership: the caller owns every buffer; the library neither keeps nor frees them.
+ * Errors: non-zero lemsm_status; the reference's assert!/panic! sites map to
+ *   LEMSM_ERR_LEN_MISMATCH (:88), LEMSM_ERR_SCALAR_OUT_OF_RANGE (:97, index in *bad_index),
+ *   LEMSM_ERR_BAD_BASE (base < 3: the reference silently truncates for base 2).
+ * Threading: a context is one GPU + one HIP stream + its workspace.  Calls on one context
+ *   are serialised by the caller; different contexts may be used concurrently.  Every entry
+ *   is synchronous: results are final on return.
+ * There is no CPU fallback: without a usable gfx950 device lemsm_create fails.
+ */
+#ifndef LEMSM_H
+#define LEMSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lemsm_ctx lemsm_ctx;
+
+enum lemsm_curve { LEMSM_BN254_G1 = 0, LEMSM_GRUMPKIN = 1 };
+
+enum lemsm_status {
+  LEMSM_OK = 0,
+  LEMSM_ERR_LEN_MISMATCH = 1,
+  LEMSM_ERR_SCALAR_OUT_OF_RANGE = 2,
+  LEMSM_ERR_BAD_BASE = 3,
+  LEMSM_ERR_BAD_CURVE = 4,
+  LEMSM_ERR_HIP = 5,
+  LEMSM_ERR_BAD_ARG = 6,
+  LEMSM_ERR_NOMEM = 7,
+  LEMSM_ERR_TOO_MANY_DIGITS = 8
+};
+
+/* ---- context ------------------------------------------------------------------------- */
+int lemsm_create(int device, lemsm_ctx** out);
+void lemsm_destroy(lemsm_ctx* ctx);
+const char* lemsm_strerror(int status);
+const char* lemsm_last_error(const lemsm_ctx* ctx);
+/* Tuning / test knobs: "window_bits" (0 = auto), "chunk" (entries per accumulate thread,
+   0 = auto), "tile" (pass-2 tile entries, 0 = auto). */
+int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value);
+/* Device-time (ms, from HIP events on the context's stream) of the last MSM call: whole
+   pipeline in [0], the dominant accumulate kernel in [1], its launch count in [2]. */
+int lemsm_last_timing(const lemsm_ctx* ctx, double out[3]);
+
+/* ---- best_multiexp ------------------------------------------------------------------- */
+/* sum_i scalars[i] * points[i]; host buffers. */
+int lemsm_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* points_affine,
+              size_t n, uint64_t out_jacobian[12]);
+int lemsm_msm_bn254_g1(lemsm_ctx* ctx, const uint8_t* scalars, const uint64_t* points_affine,
+                       size_t n, uint64_t out_jacobian[12]);
+int lemsm_msm_grumpkin(lemsm_ctx* ctx, const uint8_t* scalars, const uint64_t* points_affine,
+                       size_t n, uint64_t out_jacobian[12]);
+/* Same with inputs already resident in this context's GPU memory (device pointers). */
+int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine,
+                     size_t n, uint64_t out_jacobian[12]);
+
+/* Window-sharded form (multi-GPU: each rank computes a range of Pippenger windows, ranks
+   exchange the small partial records, everyone combines).  lemsm_msm_plan reports the number
+   of windows and the byte size of one window's partial record for an n-point MSM. */
+int lemsm_msm_plan(const lemsm_ctx* ctx, int curve, size_t n, uint32_t* num_windows,
+                   size_t* partial_bytes_per_window);
+int lemsm_msm_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars,
+                             const void* d_points_affine, size_t n, uint32_t win_begin,
+                             uint32_t win_end, uint8_t* out_partials /* (win_end-win_begin) records */);
+int lemsm_msm_combine(const lemsm_ctx* ctx, int curve, size_t n, const uint8_t* partials_all_windows,
+                      uint64_t out_jacobian[12]);
+
+/* ---- negabase decomposition ---------------------------------------------------------- */
+int lemsm_num_digits(int curve, uint8_t base, uint32_t* d);
+/* digits[i*d + k] = k-th negabase digit (LSB first, in [0,base)) of scalar i, zero padded /
+   truncated to d exactly like `.chain(repeat(0)).take(d)` (src/argument_witness_calc.rs:99). */
+int lemsm_negbase_decompose_batch(lemsm_ctx* ctx, const uint8_t* scalars, size_t n, uint8_t base,
+                                  uint32_t d, uint8_t* digits);
+
+/* ---- compute_lhs_witness MSM core ---------------------------------------------------- */
+/* carry = sum_j scalars[j]*pts[j] via the Horner-in-(-base) recursion over negabase digits.
+   out_carries (optional, d x 12 limbs): carry after each digit position, MSB first -- the
+   value the reference negates and pushes at :127.  Scalars must be < isqrt(order)+2 (:97). */
+int lemsm_lhs_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* pts_jacobian,
+                  size_t n, uint8_t base, uint64_t out_carry[12], uint64_t* out_carries,
+                  size_t* bad_index);
+int lemsm_lhs_msm_grumpkin(lemsm_ctx* ctx, const uint8_t* scalars, const uint64_t* pts_jacobian,
+                           size_t n, uint8_t base, uint64_t out_carry[12], uint64_t* out_carries,
+                           size_t* bad_index);
+int lemsm_lhs_msm_bn254_g1(lemsm_ctx* ctx, const uint8_t* scalars, const uint64_t* pts_jacobian,
+                           size_t n, uint8_t base, uint64_t out_carry[12], uint64_t* out_carries,
+                           size_t* bad_index);
+/* Device-resident form; points already affine (n x 8 limbs). */
+int lemsm_lhs_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine,
+                         size_t n, uint8_t base, uint64_t out_carry[12], uint64_t* out_carries,
+                         size_t* bad_index);
+/* Digit-position-sharded form for multi-GPU. */
+int lemsm_lhs_plan(int curve, uint8_t base, uint32_t* num_positions, size_t* partial_bytes_per_position);
+int lemsm_lhs_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine,
+                             size_t n, uint8_t base, uint32_t pos_begin, uint32_t pos_end,
+                             uint8_t* out_partials, size_t* bad_index);
+int lemsm_lhs_combine(int curve, uint8_t base, const uint8_t* partials_all_positions,
+                      uint64_t out_carry[12], uint64_t* out_carries);
+
+/* ---- precompute_multiplicities ------------------------------------------------------- */
+/* out[(k-1)] = k * pt for k = 1..base-1 (Jacobian), for each of n points:
+   out_jacobian[(j*(base-1) + (k-1))*12 .. +12]. */
+int lemsm_precompute_multiplicities(lemsm_ctx* ctx, int curve, const uint64_t* pts_jacobian, size_t n,
+                                    uint8_t base, uint64_t* out_jacobian);
+
+/* ---- helpers ------------------------------------------------------------------------- */
+/* Jacobian -> canonical comparison form: affine x||y, 32-byte little-endian canonical
+   (non-Montgomery) integers; identity = 64 zero bytes. */
+int lemsm_jacobian_to_canonical(int curve, const uint64_t jacobian[12], uint8_t out[64]);
+/* Device memory helpers so that non-HIP hosts can stage resident inputs. */
+int lemsm_device_alloc(lemsm_ctx* ctx, size_t bytes, void** out);
+int lemsm_device_free(lemsm_ctx* ctx, void* p);
+int lemsm_device_upload(lemsm_ctx* ctx, void* dst, const void* src, size_t bytes);
+int lemsm_device_download(lemsm_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* P_i = (i+1) * Q on the device (affine, n x 8 limbs): synthetic bench/test inputs with a
+   known discrete-log relation (sum s_i P_i == (sum s_i (i+1)) Q). */
+int lemsm_device_gen_walk(lemsm_ctx* ctx, int curve, const uint64_t q_affine[8], size_t n, void* d_points_out);
+
+/* ---- debug / known-answer hooks used by the parity tests ----------------------------- */
+int lemsm_debug_montmul(lemsm_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int lemsm_debug_fieldop(lemsm_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int lemsm_debug_pointop(lemsm_ctx* ctx, int curve, int op, const uint64_t* acc_xyzz, const uint64_t* q,
+                        uint64_t* out_xyzz, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEMSM_H */
