@@ -15,6 +15,7 @@
 #pragma once
 #include "plan.h"
 #include "xyzz.cuh"
+#include "xyzz29.cuh"
 
 namespace lemsm {
 
@@ -262,12 +263,12 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
 // chunk) that covers its whole bucket is stored to bucket_sum[key]; otherwise it becomes an
 // edge record (at most two per thread: first and last segment) for the next level.
 // ------------------------------------------------------------------------------------
-template <class F>
+template <class G>
 __global__ __launch_bounds__(256) void k_accum1(GroupPlan pl, const u32* __restrict__ sorted,
                                                 const u32* __restrict__ bucket_start, const u32* __restrict__ meta,
                                                 const uint4* __restrict__ points, char* __restrict__ bucket_sum,
                                                 u32* __restrict__ rec_key, char* __restrict__ rec_pt) {
-  typedef XYZZ<F> G;
+  typedef typename G::F_ F;
   typedef typename F::fe fe;
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   if (t >= pl.nthr1) return;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_accum1(GroupPlan pl, const u32* __restr
       kbeg = i; seg_begin = i;
       G::set_identity(acc);
     }
-    if (!(F::is_zero(px) && F::is_zero(py))) {
+    if (!G::aff_is_identity(px, py)) {
       F::cneg(py, py, (e >> 31) != 0);
       G::madd(acc, px, py);
     }
@@ -343,11 +344,10 @@ __global__ __launch_bounds__(256) void k_accum1(GroupPlan pl, const u32* __restr
 // level >= 2: segmented reduction of edge records (XYZZ + XYZZ).  Same completeness rule,
 // decided from the neighbouring record keys.  R = number of input records.
 // ------------------------------------------------------------------------------------
-template <class F>
+template <class G>
 __global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, const u32* __restrict__ in_key,
                                                    const char* __restrict__ in_pt, char* __restrict__ bucket_sum,
                                                    u32* __restrict__ out_key, char* __restrict__ out_pt) {
-  typedef XYZZ<F> G;
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   const u64 c0_64 = (u64)t * L;
   if (c0_64 >= R) return;
@@ -411,10 +411,9 @@ struct PyrTask {
   u32 stride, phase, count, src_valid;
 };
 
-template <class F>
+template <class G>
 __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tasks, u32 ntasks, u32 nwin,
                                                  u32 max_count, char* __restrict__ arena) {
-  typedef XYZZ<F> G;
   u32 gid = blockIdx.x * 256 + threadIdx.x;
   u32 per_task = max_count * nwin;
   u32 ti = gid / per_task;
@@ -444,6 +443,20 @@ __global__ void k_copy_points(const CopyTask* __restrict__ tasks, u32 ntasks, u3
   if (tk.src_idx < tk.src_valid_idx)
     v = reinterpret_cast<const uint4*>(arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride + tk.src_idx) * 128)[word];
   reinterpret_cast<uint4*>(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride) * 128)[word] = v;
+}
+
+// ------------------------------------------------------------------------------------
+// ABI points (x*2^256, canonical) -> the hot kernels' domain (x*2^261, canonical), once per MSM.
+// (0,0) (the identity) maps to (0,0).
+// ------------------------------------------------------------------------------------
+template <class F29>
+__global__ __launch_bounds__(256) void k_convert_points(const uint4* __restrict__ in, uint4* __restrict__ out, u32 n) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;   // one thread per coordinate
+  if (i >= 2 * n) return;
+  typename F29::fe a, r;
+  F29::load(a, in + 2 * (size_t)i);
+  F29::from_abi(r, a);
+  F29::store(out + 2 * (size_t)i, r);
 }
 
 // ------------------------------------------------------------------------------------

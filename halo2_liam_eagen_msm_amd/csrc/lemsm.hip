@@ -19,8 +19,12 @@ using namespace lemsm;
 
 namespace {
 
-typedef Field32<FqParams> FqDev;   // BN254 G1 coordinates
+typedef Field32<FqParams> FqDev;   // BN254 G1 coordinates (strict 32-bit limbs: ABI-facing kernels)
 typedef Field32<FrParams> FrDev;   // Grumpkin coordinates
+typedef XYZZ<FqDev> GqStrict;      // point arithmetic of the pipeline, strict field (A/B + reference)
+typedef XYZZ<FrDev> GrStrict;
+typedef XYZZ29<Field29<Fq29Params>> GqLazy;   // lazy radix-2^29 field: the default hot path
+typedef XYZZ29<Field29<Fr29Params>> GrLazy;
 
 // scalar-field orders as 8 x u32 (BN254 G1: r, Grumpkin: p) and isqrt(order)+2
 const u32 ORDER_R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
@@ -48,7 +52,7 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0;
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   std::map<u64, DevBuf> pyr_cache;   // task tables keyed by (nb, gw)
 };
@@ -309,7 +313,7 @@ u32 max_group_windows(u32 nb) {
 
 // Runs one window group [w0,w1): sort + accumulate + reduce; results (gw x (L+1) XYZZ points)
 // are left in the arena's out area and copied to d_out (device) + gslot.
-template <class F, class Src>
+template <class G, class Src>
 int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
               char* ws_base, char* d_out /* device, gw*(L+1)*128 bytes */, bool time_it) {
   hipStream_t st = ctx->stream;
@@ -340,7 +344,7 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
                      w.bucket_start, w.bucket_cursor, w.sorted);
 
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
-  hipLaunchKernelGGL((k_accum1<F>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, w.sorted, w.bucket_start, w.meta,
+  hipLaunchKernelGGL((k_accum1<G>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, w.sorted, w.bucket_start, w.meta,
                      (const uint4*)d_points, w.arena + (size_t)ar.bucket_off * 128, w.rec_key_a, w.rec_pt_a);
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
 
@@ -350,7 +354,7 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
     u32* ik = w.rec_key_a; char* ip = w.rec_pt_a; u32* ok = w.rec_key_b; char* op = w.rec_pt_b;
     for (;;) {
       u32 nthr = (R + L2_RECORDS - 1) / L2_RECORDS;
-      hipLaunchKernelGGL((k_segreduce<F>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, L2_RECORDS, ik, ip,
+      hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, L2_RECORDS, ik, ip,
                          w.arena + (size_t)ar.bucket_off * 128, ok, op);
       if (nthr == 1) break;
       R = 2 * nthr;
@@ -364,7 +368,7 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
       auto& tasks = pp.steps[s - 1];
       u32 maxc = pp.step_max_count[s - 1];
       size_t threads = (size_t)tasks.size() * maxc * gw;
-      hipLaunchKernelGGL((k_pyramid<F>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, w.tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
+      hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, w.tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
       toff += tasks.size();
     }
     u32 cthreads = gw * 8;
@@ -385,12 +389,20 @@ size_t group_ws_bytes(const GroupPlan& pl, u32 nbp, u32 L) {
 
 // Generic windowed bucket pipeline over window range [wb,we): fills host_out with
 // (we-wb) x (L+1) XYZZ points, summed over slabs.
-template <class P64, class F, class MakeSrc>
+// multiply every coordinate by 2^-5: records of the lazy path are x*2^261, the host works on x*2^256
+template <class P64>
+void from_converted_domain(std::vector<host::pt>& v) {
+  typedef host::HF<P64> F;
+  host::fe k251 = {{0, 0, 0, 0x0800000000000000ULL}};   // 2^251 (< N): montmul(a, 2^251) = a * 2^-5
+  for (auto& p : v) { p.x = F::mul(p.x, k251); p.y = F::mul(p.y, k251); p.zz = F::mul(p.zz, k251); p.zzz = F::mul(p.zzz, k251); }
+}
+
+template <class P64, class G, class MakeSrc>
 int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 wb, u32 we, u32 d,
                 const void* d_points, std::vector<host::pt>& host_out) {
-  typedef host::HG<P64> G;
+  typedef host::HG<P64> HGp;
   u32 nw = we - wb;
-  host_out.assign((size_t)nw * (L + 1), G::identity());
+  host_out.assign((size_t)nw * (L + 1), HGp::identity());
   if (n == 0 || nw == 0) return LEMSM_OK;
   hipStream_t st = ctx->stream;
   const size_t SLAB = (size_t)1 << MAX_SLAB_LOG;
@@ -404,31 +416,39 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
       need = std::max(need, group_ws_bytes(pl, nbp, L));
     }
   }
-  size_t out_bytes = (size_t)nw * (L + 1) * 128;
-  int rc = reserve(ctx, ctx->ws, need + out_bytes + 4096);
+  need = align_up(need, 256);
+  size_t out_bytes = align_up((size_t)nw * (L + 1) * 128, 256);
+  size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
+  int rc = reserve(ctx, ctx->ws, need + out_bytes + conv_bytes + 4096);
   if (rc) return rc;
   char* ws_base = (char*)ctx->ws.p;
-  char* d_out = ws_base + align_up(need, 256);
+  char* d_out = ws_base + need;
+  char* d_conv = d_out + out_bytes;
   std::vector<host::pt> tmp((size_t)nw * (L + 1));
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
   for (size_t s0 = 0; s0 < n; s0 += SLAB) {
     u32 sn = (u32)std::min(SLAB, n - s0);
+    const char* pts = (const char*)d_points + s0 * 64;
+    if constexpr (G::CONVERTED_DOMAIN) {
+      hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, st, (const uint4*)pts, (uint4*)d_conv, sn);
+      pts = d_conv;
+    }
     for (u32 g0 = wb; g0 < we; g0 += gmax) {
       u32 g1 = std::min(we, g0 + gmax);
       GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, g0, g1, d);
       auto src = make_src(s0, sn);
-      rc = run_group<F>(ctx, src, pl, nbp, L, (const char*)d_points + s0 * 64, ws_base,
-                        d_out + (size_t)(g0 - wb) * (L + 1) * 128, true);
+      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base, d_out + (size_t)(g0 - wb) * (L + 1) * 128, true);
       if (rc) return rc;
       HIPCHK(ctx, hipStreamSynchronize(st));
       float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
       ctx->t_accum_ms += ms; ctx->n_accum++;
     }
-    HIPCHK(ctx, hipMemcpyAsync(tmp.data(), d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(tmp.data(), d_out, (size_t)nw * (L + 1) * 128, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    if constexpr (G::CONVERTED_DOMAIN) from_converted_domain<P64>(tmp);
     if (s0 == 0) host_out = tmp;
-    else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = G::add(host_out[i], tmp[i]);
+    else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = HGp::add(host_out[i], tmp[i]);
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
@@ -457,7 +477,7 @@ void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W x (L+1) */, u64 
   G::to_jacobian(acc, out);
 }
 
-template <class P64, class F>
+template <class P64, class G>
 int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, u32 wb, u32 we,
                   std::vector<host::pt>& out) {
   MsmPlan mp = make_msm_plan(ctx, curve, n);
@@ -466,7 +486,7 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
     PipSrc s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
     memcpy(s.kadd, mp.kadd, 32); return s;
   };
-  return run_windows<P64, F>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, out);
+  return run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, out);
 }
 
 int check_curve(lemsm_ctx* ctx, int curve) {
@@ -512,7 +532,7 @@ int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const
   return LEMSM_OK;
 }
 
-template <class P64, class F>
+template <class P64, class G>
 int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, const LhsPlan& lp,
                   u32 pb, u32 pe, std::vector<host::pt>& out, size_t* bad_index) {
   if (pb > pe || pe > lp.d) return fail(ctx, LEMSM_ERR_BAD_ARG, "position range out of bounds");
@@ -525,7 +545,7 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   // NegSrc indexes digitsT[w * pl.n + j] with pl.n = slab size, so multi-slab inputs need the
   // full row stride: restrict the lhs path to one slab (n <= 2^24) for now.
   if (n > ((size_t)1 << MAX_SLAB_LOG)) return fail(ctx, LEMSM_ERR_BAD_ARG, "lhs path supports n <= 2^24 per call");
-  rc = run_windows<P64, F>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, out);
+  rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, out);
   if (rc) return rc;
   u32 err[2] = {0xffffffffu, 0};
   if (n) {
@@ -552,6 +572,26 @@ void lhs_combine_t(const LhsPlan& lp, const host::pt* recs /* d x (L+1), positio
     if (out_carries) G::to_jacobian(carry, out_carries + 12 * (size_t)it);
   }
   G::to_jacobian(carry, out_carry);
+}
+
+// field selection: option "field" 0 = lazy radix-2^29 (default), 1 = strict 32-bit limbs
+int msm_partial_dispatch(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, u32 wb, u32 we,
+                         std::vector<host::pt>& out) {
+  if (ctx->opt_field == 1) {
+    if (curve == LEMSM_BN254_G1) return msm_partial_t<host::FqParams64, GqStrict>(ctx, curve, d_scalars, d_points, n, wb, we, out);
+    return msm_partial_t<host::FrParams64, GrStrict>(ctx, curve, d_scalars, d_points, n, wb, we, out);
+  }
+  if (curve == LEMSM_BN254_G1) return msm_partial_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, wb, we, out);
+  return msm_partial_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, wb, we, out);
+}
+int lhs_partial_dispatch(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, const LhsPlan& lp,
+                         u32 pb, u32 pe, std::vector<host::pt>& out, size_t* bad_index) {
+  if (ctx->opt_field == 1) {
+    if (curve == LEMSM_BN254_G1) return lhs_partial_t<host::FqParams64, GqStrict>(ctx, curve, d_scalars, d_points, n, lp, pb, pe, out, bad_index);
+    return lhs_partial_t<host::FrParams64, GrStrict>(ctx, curve, d_scalars, d_points, n, lp, pb, pe, out, bad_index);
+  }
+  if (curve == LEMSM_BN254_G1) return lhs_partial_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, lp, pb, pe, out, bad_index);
+  return lhs_partial_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, lp, pb, pe, out, bad_index);
 }
 
 template <class F>
@@ -671,6 +711,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return LEMSM_ERR_BAD_ARG; ctx->opt_window_bits = value; }
   else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
+  else if (!strcmp(name, "field")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_field = value; }
   else return LEMSM_ERR_BAD_ARG;
   return LEMSM_OK;
 }
@@ -695,8 +736,7 @@ int lemsm_msm_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, c
   int rc = check_curve(ctx, curve); if (rc) return rc;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::vector<host::pt> out;
-  if (curve == LEMSM_BN254_G1) rc = msm_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, win_begin, win_end, out);
-  else rc = msm_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, win_begin, win_end, out);
+  rc = msm_partial_dispatch(ctx, curve, d_scalars, d_points, n, win_begin, win_end, out);
   if (rc) return rc;
   memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
   return LEMSM_OK;
@@ -720,15 +760,10 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   HIPCHK(ctx, hipSetDevice(ctx->device));
   MsmPlan mp = make_msm_plan(ctx, curve, n);
   std::vector<host::pt> recs;
-  if (curve == LEMSM_BN254_G1) {
-    rc = msm_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, 0, mp.W, recs);
-    if (rc) return rc;
-    msm_combine_t<host::FqParams64>(mp, recs.data(), out);
-  } else {
-    rc = msm_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, 0, mp.W, recs);
-    if (rc) return rc;
-    msm_combine_t<host::FrParams64>(mp, recs.data(), out);
-  }
+  rc = msm_partial_dispatch(ctx, curve, d_scalars, d_points, n, 0, mp.W, recs);
+  if (rc) return rc;
+  if (curve == LEMSM_BN254_G1) msm_combine_t<host::FqParams64>(mp, recs.data(), out);
+  else msm_combine_t<host::FrParams64>(mp, recs.data(), out);
   return LEMSM_OK;
 }
 
@@ -787,8 +822,7 @@ int lemsm_lhs_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, c
   LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::vector<host::pt> out;
-  if (curve == LEMSM_BN254_G1) rc = lhs_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, lp, pos_begin, pos_end, out, bad_index);
-  else rc = lhs_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, lp, pos_begin, pos_end, out, bad_index);
+  rc = lhs_partial_dispatch(ctx, curve, d_scalars, d_points, n, lp, pos_begin, pos_end, out, bad_index);
   if (rc) return rc;
   memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
   return LEMSM_OK;
@@ -812,15 +846,10 @@ int lemsm_lhs_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const
   LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::vector<host::pt> recs;
-  if (curve == LEMSM_BN254_G1) {
-    rc = lhs_partial_t<host::FqParams64, FqDev>(ctx, curve, d_scalars, d_points, n, lp, 0, lp.d, recs, bad_index);
-    if (rc) return rc;
-    lhs_combine_t<host::FqParams64>(lp, recs.data(), out_carry, out_carries);
-  } else {
-    rc = lhs_partial_t<host::FrParams64, FrDev>(ctx, curve, d_scalars, d_points, n, lp, 0, lp.d, recs, bad_index);
-    if (rc) return rc;
-    lhs_combine_t<host::FrParams64>(lp, recs.data(), out_carry, out_carries);
-  }
+  rc = lhs_partial_dispatch(ctx, curve, d_scalars, d_points, n, lp, 0, lp.d, recs, bad_index);
+  if (rc) return rc;
+  if (curve == LEMSM_BN254_G1) lhs_combine_t<host::FqParams64>(lp, recs.data(), out_carry, out_carries);
+  else lhs_combine_t<host::FrParams64>(lp, recs.data(), out_carry, out_carries);
   return LEMSM_OK;
 }
 

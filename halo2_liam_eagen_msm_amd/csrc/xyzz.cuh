@@ -18,7 +18,10 @@ namespace lemsm {
 
 template <class F>
 struct XYZZ {
+  typedef F F_;
   typedef typename F::fe fe;
+  static constexpr bool CONVERTED_DOMAIN = false;
+  static __device__ __forceinline__ bool aff_is_identity(const fe& x, const fe& y) { return F::is_zero(x) && F::is_zero(y); }
   struct pt { fe x, y, zz, zzz; };
   struct aff { fe x, y; };
 

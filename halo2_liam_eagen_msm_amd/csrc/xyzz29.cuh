@@ -1,0 +1,153 @@
+// XYZZ group law over the lazy radix-2^29 field (field29.cuh): the arithmetic of the hot
+// kernels (k_accum1, k_segreduce, k_pyramid).  Same formulas and the same complete case
+// handling as xyzz.cuh; what differs is how the field operations are composed so that no
+// operand of a product ever exceeds the limb bound of field29.cuh:
+//   * differences of two normalised values (|limb| < 2^29) feed products directly,
+//   * X3 = R^2 - PPP - 2Q is ONE Montgomery reduction: (2N - PPP - 2Q) rides in on the upper
+//     columns of R*R, so X3 comes out normalised,
+//   * Y3 = R*(Q - X3) - Y1*PPP is ONE reduction of a two-product column sum.
+// A mixed addition is 7 multiplications + 2 squarings worth of products and 9 reductions
+// (~2,000 VALU instructions).
+//
+// Points in memory: 4 x 32 bytes (x, y, zz, zzz), canonical integers of the 2^261-domain
+// residues; identity = all zero (zz == 0).
+#pragma once
+#include "field29.cuh"
+
+namespace lemsm {
+
+template <class F>
+struct XYZZ29 {
+  typedef F F_;
+  typedef typename F::fe fe;
+  static constexpr bool CONVERTED_DOMAIN = true;   // coordinates are x*2^261, see field29.cuh
+  static __device__ __forceinline__ bool aff_is_identity(const fe& x, const fe& y) { return F::limbs_zero(x) && F::limbs_zero(y); }
+  struct pt { fe x, y, zz, zzz; };
+
+  static __device__ __forceinline__ void set_identity(pt& p) {
+    F::set_zero(p.x); F::set_zero(p.y); F::set_zero(p.zz); F::set_zero(p.zzz);
+  }
+  // zz of a valid non-identity point is never == 0 mod N, and the identity is always written
+  // as literal zeros, so the limb pattern test is exact.
+  static __device__ __forceinline__ bool is_identity(const pt& p) { return F::limbs_zero(p.zz); }
+
+  // hi = 2N - ppp - 2q  (lazy limbs; only ever added into the upper columns of a product)
+  static __device__ __forceinline__ void hi_term(fe& t, const fe& ppp, const fe& q) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      i32 n2 = (i32)((((u32)F::P_::N[i] << 1) & (u32)F::MASK) | (i ? ((u32)F::P_::N[i - 1] >> 28) : 0u));
+      t.l[i] = n2 - ppp.l[i] - 2 * q.l[i];
+    }
+  }
+
+  // P == 0 (mod N)  <=>  PP = P^2 * 2^-261 is 0 or N as an integer (PP in [0, 1.2N)).
+  static __device__ __forceinline__ bool pp_is_zero(const fe& pp) {
+    if (pp.l[0] != 0 && pp.l[0] != F::P_::N[0]) return false;
+    i32 z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { z |= pp.l[i]; e |= pp.l[i] ^ F::P_::N[i]; }
+    return z == 0 || e == 0;
+  }
+
+  // r = 2 * (X, Y, ZZ, ZZZ) (dbl-2008-s-1, a = 0); for an affine input pass zz = zzz = one and
+  // AFFINE = true.  Rare path (equal points meet in a bucket): generous normalisation, out of line.
+  template <bool AFFINE>
+  static __device__ __noinline__ void dbl_impl(pt& r, const pt& p) {
+    fe U, V, W, S, M, t, nW, x3;
+    F::add(U, p.y, p.y); F::wnorm(U);                 // U = 2Y
+    F::sqr(V, U);                                     // V = U^2
+    F::mul(W, U, V);                                  // W = U*V
+    F::mul(S, p.x, V);                                // S = X*V
+    F::sqr(t, p.x); F::add(M, t, t); F::add(M, M, t); F::wnorm(M);   // M = 3X^2
+    // X3 = M^2 - 2S :  hi = 2N - 0 - 2S
+    fe zero; F::set_zero(zero);
+    hi_term(t, zero, S);
+    F::mul_addhi(x3, M, M, t);
+    // Y3 = M*(S - X3) - W*Y
+    F::sub(t, S, x3); F::neg(nW, W);
+    fe y = p.y; F::wnorm(y);
+    F::mul2(r.y, M, t, nW, y);
+    r.x = x3;
+    if (AFFINE) { r.zz = V; r.zzz = W; }
+    else { F::mul(r.zz, V, p.zz); F::mul(r.zzz, W, p.zzz); }
+  }
+
+  // acc += (x2, y2): affine, non-identity, 2^261-domain normalised coordinates; y2 may carry
+  // a negation (|limb| < 2^29).
+  static __device__ __forceinline__ void madd(pt& acc, const fe& x2, const fe& y2) {
+    if (is_identity(acc)) {
+      acc.x = x2; acc.y = y2; F::wnorm(acc.y); F::set_one(acc.zz); F::set_one(acc.zzz);
+      return;
+    }
+    fe U2, S2, P, R, PP;
+    F::mul(U2, x2, acc.zz);
+    F::mul(S2, y2, acc.zzz);
+    F::sub(P, U2, acc.x);
+    F::sub(R, S2, acc.y);
+    F::sqr(PP, P);
+    if (pp_is_zero(PP)) {                 // same x: doubling or cancellation
+      if (F::is_zero_mod(R)) {
+        pt a; a.x = x2; a.y = y2; F::set_one(a.zz); F::set_one(a.zzz);
+        dbl_impl<true>(acc, a);
+      } else set_identity(acc);
+      return;
+    }
+    fe PPP, Q, t, nY;
+    F::mul(PPP, P, PP);
+    F::mul(Q, acc.x, PP);
+    hi_term(t, PPP, Q);
+    F::neg(nY, acc.y);
+    F::mul_addhi(acc.x, R, R, t);                  // X3 = R^2 - PPP - 2Q
+    F::sub(t, Q, acc.x);
+    F::mul2(acc.y, R, t, nY, PPP);                 // Y3 = R(Q - X3) - Y1*PPP
+    F::mul(acc.zz, acc.zz, PP);
+    F::mul(acc.zzz, acc.zzz, PPP);
+  }
+
+  // acc += q (both XYZZ, any inputs)
+  static __device__ __forceinline__ void add(pt& acc, const pt& q) {
+    if (is_identity(q)) return;
+    if (is_identity(acc)) { acc = q; return; }
+    fe U1, U2, S1, S2, P, R, PP;
+    F::mul(U1, acc.x, q.zz);
+    F::mul(U2, q.x, acc.zz);
+    F::mul(S1, acc.y, q.zzz);
+    F::mul(S2, q.y, acc.zzz);
+    F::sub(P, U2, U1);
+    F::sub(R, S2, S1);
+    F::sqr(PP, P);
+    if (pp_is_zero(PP)) {
+      if (F::is_zero_mod(R)) { pt t = acc; dbl_impl<false>(acc, t); }
+      else set_identity(acc);
+      return;
+    }
+    fe PPP, Q, t, nS;
+    F::mul(PPP, P, PP);
+    F::mul(Q, U1, PP);
+    hi_term(t, PPP, Q);
+    F::neg(nS, S1);
+    F::mul_addhi(acc.x, R, R, t);
+    F::sub(t, Q, acc.x);
+    F::mul2(acc.y, R, t, nS, PPP);
+    F::mul(t, acc.zz, q.zz); F::mul(acc.zz, t, PP);
+    F::mul(t, acc.zzz, q.zzz); F::mul(acc.zzz, t, PPP);
+  }
+
+  static __device__ __forceinline__ void load(pt& p, const void* mem) {
+    const char* m = reinterpret_cast<const char*>(mem);
+    F::load(p.x, m); F::load(p.y, m + 32); F::load(p.zz, m + 64); F::load(p.zzz, m + 96);
+  }
+  static __device__ __forceinline__ void store(void* mem, const pt& p) {
+    char* m = reinterpret_cast<char*>(mem);
+    if (is_identity(p)) {
+      uint4 z = make_uint4(0, 0, 0, 0);
+      uint4* q = reinterpret_cast<uint4*>(m);
+#pragma unroll
+      for (int i = 0; i < 8; i++) q[i] = z;
+      return;
+    }
+    F::store(m, p.x); F::store(m + 32, p.y); F::store(m + 64, p.zz); F::store(m + 96, p.zzz);
+  }
+};
+
+}  // namespace lemsm

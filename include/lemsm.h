@@ -71,7 +71,8 @@ void lemsm_destroy(lemsm_ctx* ctx);
 const char* lemsm_strerror(int status);
 const char* lemsm_last_error(const lemsm_ctx* ctx);
 /* Tuning / test knobs: "window_bits" (0 = auto), "chunk" (entries per accumulate thread,
-   0 = auto), "tile" (pass-2 tile entries, 0 = auto). */
+   0 = auto), "tile" (pass-2 tile entries, 0 = auto), "field" (0 = lazy radix-2^29 arithmetic, the default;
+   1 = strict 32-bit-limb arithmetic, kept for A/B and as an in-library cross-check). */
 int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value);
 /* Device-time (ms, from HIP events on the context's stream) of the last MSM call: whole
    pipeline in [0], the dominant accumulate kernel in [1], its launch count in [2]. */

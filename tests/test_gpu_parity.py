@@ -16,6 +16,16 @@ from oracle import cref, pyref
 
 pytestmark = pytest.mark.gpu
 
+FIELDS = [0, 1]   # 0 = lazy radix-2^29 arithmetic (default hot path), 1 = strict 32-bit limbs
+
+
+@pytest.fixture(params=FIELDS, ids=["lazy29", "strict32"])
+def fctx(ctx, request):
+    """context with the field arithmetic of the hot kernels selected"""
+    ctx.set_option("field", request.param)
+    yield ctx
+    ctx.set_option("field", 0)
+
 
 # ------------------------------------------------------------------ field / group KATs
 def test_device_montmul_reference_fr_chains(ctx):
@@ -95,7 +105,8 @@ def test_device_point_ops_complete(ctx, curve):
 
 
 # ------------------------------------------------------------------ golden vectors
-def test_golden_msm_vectors(ctx):
+def test_golden_msm_vectors(fctx):
+    ctx = fctx
     for v in load_json("msm_vectors.json")["msm"]:
         c = pyref.CURVES[v["curve"]]
         out = ctx.msm(c.cid, golden_scalars(v["scalars"]), golden_points_raw(c, v["points"]))
@@ -103,7 +114,8 @@ def test_golden_msm_vectors(ctx):
         assert canon(c, out) == bytes.fromhex(v["expected"])
 
 
-def test_golden_lhs_vectors(ctx):
+def test_golden_lhs_vectors(fctx):
+    ctx = fctx
     for v in load_json("msm_vectors.json")["lhs"]:
         c = pyref.CURVES[v["curve"]]
         sc = golden_scalars(v["scalars"])
@@ -119,7 +131,8 @@ def test_golden_lhs_vectors(ctx):
 # ------------------------------------------------------------------ MSM vs oracle, seeded
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 255, 1000, 4097])
-def test_msm_matches_oracle(ctx, curve, n):
+def test_msm_matches_oracle(fctx, curve, n):
+    ctx = fctx
     pts = cref.gen_points(curve.cid, 1000 + n, n)
     sc = cref.gen_scalars(curve.cid, 2000 + n, n)
     out = ctx.msm(curve.cid, sc, pts)
@@ -129,7 +142,8 @@ def test_msm_matches_oracle(ctx, curve, n):
 
 @pytest.mark.parametrize("c_bits", [2, 3, 5, 8, 11, 13, 16])
 @pytest.mark.parametrize("chunk", [1, 7, 64])
-def test_msm_window_and_chunk_sweep(ctx, c_bits, chunk):
+def test_msm_window_and_chunk_sweep(fctx, c_bits, chunk):
+    ctx = fctx
     """every window width (bins with LB 0..7) and ragged chunk lengths give the same group element"""
     curve = pyref.BN254_G1
     n = 700
@@ -144,7 +158,8 @@ def test_msm_window_and_chunk_sweep(ctx, c_bits, chunk):
 
 
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
-def test_msm_adversarial_shapes(ctx, curve):
+def test_msm_adversarial_shapes(fctx, curve):
+    ctx = fctx
     n = 600
     base_pts = cref.gen_points(curve.cid, 9, 4)
     sc1 = cref.gen_scalars(curve.cid, 10, 1)
@@ -169,7 +184,8 @@ def test_msm_adversarial_shapes(ctx, curve):
     assert canon(curve, ctx.msm(curve.cid, sc, pts)) == canon(curve, cref.msm_naive(curve.cid, sc, pts))
 
 
-def test_msm_skewed_buckets_all_windows_equal(ctx):
+def test_msm_skewed_buckets_all_windows_equal(fctx):
+    ctx = fctx
     """all scalars equal with c=16 windows: every window has a single bucket holding all points"""
     curve = pyref.BN254_G1
     n = 3000
@@ -235,7 +251,8 @@ def test_negbase_batch_matches_oracle(ctx, base):
 
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("base,n", [(5, 400), (16, 700), (3, 50), (255, 120), (17, 33)])
-def test_lhs_matches_oracle(ctx, curve, base, n):
+def test_lhs_matches_oracle(fctx, curve, base, n):
+    ctx = fctx
     pts_aff = cref.gen_points(curve.cid, 60 + n, n)
     sc = cref.gen_scalars(curve.cid, 61 + n, n, half=True)
     pts = jacobian_with_random_z(curve, pts_aff, 62 + n)
@@ -249,7 +266,8 @@ def test_lhs_matches_oracle(ctx, curve, base, n):
     assert canon(curve, carry) == canon(curve, ctx.msm(curve.cid, sc, pts_aff))
 
 
-def test_lhs_reference_test_shape(ctx):
+def test_lhs_reference_test_shape(fctx):
+    ctx = fctx
     """lhs_test itself: Grumpkin, base 5, one (scalar, point) pair replicated; here n = 2000"""
     c = pyref.GRUMPKIN
     n = 2000
