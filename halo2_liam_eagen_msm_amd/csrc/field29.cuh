@@ -100,75 +100,14 @@ struct Field29 {
     a.l[8] += c;
   }
 
-  // r = (a*b [+ c*d] + hi * 2^261) / 2^261 mod N, exactly normalised.  hi: lazy limbs.
-  template <bool TWO, bool HI>
-  static __device__ __forceinline__ void mont(fe& r, const fe& a, const fe& b, const fe& c, const fe& d, const fe& hi) {
-    i64 acc = 0;
-    i32 m[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) {
-        smad(acc, a.l[i], b.l[k - i]);
-        if (TWO) smad(acc, c.l[i], d.l[k - i]);
-      }
-#pragma unroll
-      for (int i = 0; i < k; i++) smadc(acc, m[i], P::N[k - i]);
-      m[k] = (i32)(((u32)acc * P::NINV) & (u32)MASK);
-      smadc(acc, m[k], P::N[0]);
-      acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-      for (int i = k - 8; i < 9; i++) {
-        smad(acc, a.l[i], b.l[k - i]);
-        if (TWO) smad(acc, c.l[i], d.l[k - i]);
-      }
-#pragma unroll
-      for (int i = k - 8; i < 9; i++) smadc(acc, m[i], P::N[k - i]);
-      if (HI) acc += (i64)hi.l[k - 9];
-      r.l[k - 9] = (i32)((u32)acc & (u32)MASK);
-      acc >>= 29;
-    }
-    if (HI) acc += (i64)hi.l[8];
-    r.l[8] = (i32)acc;
-  }
-  static __device__ __forceinline__ void mul(fe& r, const fe& a, const fe& b) { mont<false, false>(r, a, b, a, b, a); }
-  // square: 36 doubled cross products + 9 squares
-  static __device__ __forceinline__ void sqr(fe& r, const fe& a) {
-    i32 a2[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) a2[i] = a.l[i] * 2;
-    i64 acc = 0;
-    i32 m[9];
-#pragma unroll
-    for (int k = 0; k < 17; k++) {
-#pragma unroll
-      for (int i = 0; i < 9; i++) {
-        int j = k - i;
-        if (j < 0 || j > 8 || i > j) continue;
-        if (i == j) smad(acc, a.l[i], a.l[i]);
-        else smad(acc, a2[i], a.l[j]);
-      }
-      if (k < 9) {
-#pragma unroll
-        for (int i = 0; i < k; i++) smadc(acc, m[i], P::N[k - i]);
-        m[k] = (i32)(((u32)acc * P::NINV) & (u32)MASK);
-        smadc(acc, m[k], P::N[0]);
-      } else {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) smadc(acc, m[i], P::N[k - i]);
-        r.l[k - 9] = (i32)((u32)acc & (u32)MASK);
-      }
-      acc >>= 29;
-    }
-    r.l[8] = (i32)acc;
-  }
-  // r = a*b/2^261 + hi
-  static __device__ __forceinline__ void mul_addhi(fe& r, const fe& a, const fe& b, const fe& hi) { mont<false, true>(r, a, b, a, b, hi); }
-  // r = (a*b + c*d)/2^261
-  static __device__ __forceinline__ void mul2(fe& r, const fe& a, const fe& b, const fe& c, const fe& d) { mont<true, false>(r, a, b, c, d, a); }
+  // Montgomery products, fully unrolled with one asm block per column (tools/gen_field29.py):
+  //   mul(r,a,b)            r = a*b / 2^261
+  //   sqr(r,a)              r = a*a / 2^261            (36 doubled cross products + 9 squares)
+  //   mul_addhi(r,a,b,hi)   r = a*b / 2^261 + hi       (hi: lazy limbs, added on the upper columns)
+  //   sqr_addhi(r,a,hi)     r = a*a / 2^261 + hi
+  //   mul2(r,a,b,c,d)       r = (a*b + c*d) / 2^261
+  // all results exactly normalised.
+#include "field29_gen.inc"
 
   // canonical representative in [0, N) with normalised limbs.  |V| < 8N on entry.
   static __device__ __forceinline__ void canon(fe& a) {

@@ -13,16 +13,9 @@
 //   src/argument_witness_calc.rs:105-127 per-digit sums S_i of the Horner recursion -> buckets
 //   halo2 best_multiexp (third party) bucket accumulation       -> PipSrc + same kernels
 #pragma once
-#include "plan.h"
-#include "xyzz.cuh"
-#include "xyzz29.cuh"
+#include "kernels_ec.cuh"
 
 namespace lemsm {
-
-static const u32 KEY_NONE = 0xffffffffu;
-
-// meta words written by k_binscan
-enum { META_M = 0, META_TILES = 1, META_WORDS = 4 };
 
 // ------------------------------------------------------------------------------------
 // digit sources
@@ -257,206 +250,19 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
   }
 }
 
-// ------------------------------------------------------------------------------------
-// level 1: segmented accumulation of the bucket-sorted entry list.
-// Thread t owns entries [t*L1, (t+1)*L1).  A segment (maximal run of one bucket inside the
-// chunk) that covers its whole bucket is stored to bucket_sum[key]; otherwise it becomes an
-// edge record (at most two per thread: first and last segment) for the next level.
-// ------------------------------------------------------------------------------------
-template <class G>
-__global__ __launch_bounds__(256) void k_accum1(GroupPlan pl, const u32* __restrict__ sorted,
-                                                const u32* __restrict__ bucket_start, const u32* __restrict__ meta,
-                                                const uint4* __restrict__ points, char* __restrict__ bucket_sum,
-                                                u32* __restrict__ rec_key, char* __restrict__ rec_pt) {
-  typedef typename G::F_ F;
-  typedef typename F::fe fe;
-  const u32 t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= pl.nthr1) return;
-  const u32 M = meta[META_M];
-  const u64 s64 = (u64)t * pl.L1;
-  const u32 r0 = 2 * t;
-  if (s64 >= M) { rec_key[r0] = KEY_NONE; rec_key[r0 + 1] = KEY_NONE; return; }
-  const u32 start = (u32)s64;
-  const u32 end = (u32)min((u64)M, s64 + pl.L1);
-
-  u32 lo = 0, hi = pl.nbins << pl.LB;   // largest key with bucket_start[key] <= start
-  while (hi - lo > 1) {
-    u32 mid = (lo + hi) >> 1;
-    if (bucket_start[mid] <= start) lo = mid; else hi = mid;
-  }
-  u32 key = lo;
-  u32 kbeg = bucket_start[key];
-  u32 kend = bucket_start[key + 1];
-  u32 seg_begin = start;
-  u32 nrec = 0;
-  u32 first_key = KEY_NONE;
-
-  typename G::pt acc; G::set_identity(acc);
-
-  auto flush = [&](u32 seg_end) {
-    bool complete = (seg_begin == kbeg) && (seg_end == kend);
-    if (complete) {
-      G::store(bucket_sum + (size_t)key * 128, acc);
-    } else {
-      u32 slot = r0 + nrec;
-      rec_key[slot] = key;
-      G::store(rec_pt + (size_t)slot * 128, acc);
-      if (nrec == 0) first_key = key;
-      nrec++;
-    }
-  };
-
-  u32 e_next = sorted[start];
-  fe nx, ny;
-  { const uint4* p = points + (size_t)(e_next & 0xffffffu) * 4; F::load(nx, p); F::load(ny, p + 2); }
-
-  for (u32 i = start; i < end; i++) {
-    u32 e = e_next; fe px = nx, py = ny;
-    if (i + 1 < end) {
-      e_next = sorted[i + 1];
-      const uint4* p = points + (size_t)(e_next & 0xffffffu) * 4;
-      F::load(nx, p); F::load(ny, p + 2);
-    }
-    if (i >= kend) {
-      flush(i);
-      do { key++; kend = bucket_start[key + 1]; } while (i >= kend);
-      kbeg = i; seg_begin = i;
-      G::set_identity(acc);
-    }
-    if (!G::aff_is_identity(px, py)) {
-      F::cneg(py, py, (e >> 31) != 0);
-      G::madd(acc, px, py);
-    }
-  }
-  flush(end);
-  // Filler rule (DESIGN.md "edge records"): a lone record is followed by an identity record of
-  // the same key, so that a bucket's run of records stays contiguous across threads (KEY_NONE is
-  // only ever written where no run can pass through).
-  if (nrec == 0) { rec_key[r0] = KEY_NONE; rec_key[r0 + 1] = KEY_NONE; }
-  else if (nrec == 1) {
-    typename G::pt id; G::set_identity(id);
-    rec_key[r0 + 1] = first_key;
-    G::store(rec_pt + (size_t)(r0 + 1) * 128, id);
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// level >= 2: segmented reduction of edge records (XYZZ + XYZZ).  Same completeness rule,
-// decided from the neighbouring record keys.  R = number of input records.
-// ------------------------------------------------------------------------------------
-template <class G>
-__global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, const u32* __restrict__ in_key,
-                                                   const char* __restrict__ in_pt, char* __restrict__ bucket_sum,
-                                                   u32* __restrict__ out_key, char* __restrict__ out_pt) {
-  const u32 t = blockIdx.x * 256 + threadIdx.x;
-  const u64 c0_64 = (u64)t * L;
-  if (c0_64 >= R) return;
-  const u32 c0 = (u32)c0_64;
-  const u32 c1 = (u32)min((u64)R, c0_64 + L);
-  const u32 r0 = 2 * t;
-  const u32 prev_key = c0 > 0 ? in_key[c0 - 1] : KEY_NONE;
-  const u32 next_key = c1 < R ? in_key[c1] : KEY_NONE;
-
-  typename G::pt acc; G::set_identity(acc);
-  u32 cur = KEY_NONE;         // key of the open segment
-  bool open_from_start = false;
-  u32 nrec = 0, first_key = KEY_NONE;
-
-  auto flush = [&](bool touches_end) {
-    bool complete = !(open_from_start && prev_key == cur) && !(touches_end && next_key == cur);
-    if (complete) {
-      G::store(bucket_sum + (size_t)cur * 128, acc);
-    } else {
-      u32 slot = r0 + nrec;
-      out_key[slot] = cur;
-      G::store(out_pt + (size_t)slot * 128, acc);
-      if (nrec == 0) first_key = cur;
-      nrec++;
-    }
-  };
-
-  for (u32 i = c0; i < c1; i++) {
-    u32 k = in_key[i];
-    if (k == KEY_NONE) {
-      if (cur != KEY_NONE) { flush(false); cur = KEY_NONE; }
-      continue;
-    }
-    if (k != cur) {
-      if (cur != KEY_NONE) flush(false);
-      cur = k;
-      open_from_start = (i == c0);
-      G::set_identity(acc);
-    }
-    typename G::pt q; G::load(q, in_pt + (size_t)i * 128);
-    G::add(acc, q);
-  }
-  if (cur != KEY_NONE) flush(true);
-  if (nrec == 0) { out_key[r0] = KEY_NONE; out_key[r0 + 1] = KEY_NONE; }
-  else if (nrec == 1) {
-    typename G::pt id; G::set_identity(id);
-    out_key[r0 + 1] = first_key;
-    G::store(out_pt + (size_t)(r0 + 1) * 128, id);
-  }
-}
-
-// ------------------------------------------------------------------------------------
-// bucket reduction: pairwise-add pyramid.  One launch per step; a step is a list of tasks
-//   dst[i] = src[(2i)*stride + phase] + src[(2i+1)*stride + phase],   i < count
-// applied to every window.  Arena offsets are in points (128 B); src indices >= src_valid
-// read as the identity (padding of non-power-of-two bucket counts).
-// ------------------------------------------------------------------------------------
-struct PyrTask {
-  u32 src_off, src_wstride;   // per-window base = src_off + w * src_wstride
-  u32 dst_off, dst_wstride;
-  u32 stride, phase, count, src_valid;
-};
-
-template <class G>
-__global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tasks, u32 ntasks, u32 nwin,
-                                                 u32 max_count, char* __restrict__ arena) {
-  u32 gid = blockIdx.x * 256 + threadIdx.x;
-  u32 per_task = max_count * nwin;
-  u32 ti = gid / per_task;
-  if (ti >= ntasks) return;
-  u32 rem = gid - ti * per_task;
-  u32 w = rem / max_count, i = rem - w * max_count;
-  PyrTask tk = tasks[ti];
-  if (i >= tk.count) return;
-  u32 ia = (2 * i) * tk.stride + tk.phase, ib = (2 * i + 1) * tk.stride + tk.phase;
-  const char* src = arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride) * 128;
-  typename G::pt a, b;
-  if (ia < tk.src_valid) G::load(a, src + (size_t)ia * 128); else G::set_identity(a);
-  if (ib < tk.src_valid) G::load(b, src + (size_t)ib * 128); else G::set_identity(b);
-  G::add(a, b);
-  G::store(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride + i) * 128, a);
-}
-
 // copy single points (task results that are already final, e.g. U_{L-1} = A^{L-1}[1])
 struct CopyTask { u32 src_off, src_wstride, dst_off, dst_wstride, src_valid_idx, src_idx; };
-__global__ void k_copy_points(const CopyTask* __restrict__ tasks, u32 ntasks, u32 nwin, char* __restrict__ arena) {
+__global__ void k_copy_points(const CopyTask* __restrict__ tasks, u32 ntasks, u32 nwin, u32 pt_bytes, char* __restrict__ arena) {
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (task, window, 16-byte word)
-  u32 word = gid & 7u; u32 r = gid >> 3;
+  u32 wpp = pt_bytes / 16;
+  u32 word = gid % wpp; u32 r = gid / wpp;
   u32 ti = r / nwin, w = r - ti * nwin;
   if (ti >= ntasks) return;
   CopyTask tk = tasks[ti];
   uint4 v = make_uint4(0, 0, 0, 0);
   if (tk.src_idx < tk.src_valid_idx)
-    v = reinterpret_cast<const uint4*>(arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride + tk.src_idx) * 128)[word];
-  reinterpret_cast<uint4*>(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride) * 128)[word] = v;
-}
-
-// ------------------------------------------------------------------------------------
-// ABI points (x*2^256, canonical) -> the hot kernels' domain (x*2^261, canonical), once per MSM.
-// (0,0) (the identity) maps to (0,0).
-// ------------------------------------------------------------------------------------
-template <class F29>
-__global__ __launch_bounds__(256) void k_convert_points(const uint4* __restrict__ in, uint4* __restrict__ out, u32 n) {
-  u32 i = blockIdx.x * 256 + threadIdx.x;   // one thread per coordinate
-  if (i >= 2 * n) return;
-  typename F29::fe a, r;
-  F29::load(a, in + 2 * (size_t)i);
-  F29::from_abi(r, a);
-  F29::store(out + 2 * (size_t)i, r);
+    v = reinterpret_cast<const uint4*>(arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride + tk.src_idx) * pt_bytes)[word];
+  reinterpret_cast<uint4*>(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride) * pt_bytes)[word] = v;
 }
 
 // ------------------------------------------------------------------------------------

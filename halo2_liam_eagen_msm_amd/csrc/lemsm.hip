@@ -36,6 +36,21 @@ const u32 BOUND_P[8] = {0xc7b81b1cu, 0xc6fb4e9fu, 0xeeb859fcu, 0x6f4d8248u, 0, 0
 const u32* order_of(int curve) { return curve == LEMSM_BN254_G1 ? ORDER_R : ORDER_P; }
 const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUND_P; }
 
+}  // namespace
+// heavy kernels are instantiated in inst_*.hip
+#define LEMSM_EXTERN_G(G)                                                                                   \
+  extern template __global__ void lemsm::k_segreduce<G>(u32, u32, const u32*, const char*, char*, u32*, char*); \
+  extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
+#define LEMSM_EXTERN_ACC(G, W) \
+  extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+LEMSM_EXTERN_G(GqStrict) LEMSM_EXTERN_G(GrStrict) LEMSM_EXTERN_G(GqLazy) LEMSM_EXTERN_G(GrLazy)
+LEMSM_EXTERN_ACC(GqStrict, 4) LEMSM_EXTERN_ACC(GrStrict, 4)
+LEMSM_EXTERN_ACC(GqLazy, 2) LEMSM_EXTERN_ACC(GqLazy, 3) LEMSM_EXTERN_ACC(GqLazy, 4)
+LEMSM_EXTERN_ACC(GrLazy, 2) LEMSM_EXTERN_ACC(GrLazy, 3) LEMSM_EXTERN_ACC(GrLazy, 4)
+extern template __global__ void lemsm::k_convert_points<Field29<Fq29Params>>(const uint4*, uint4*, u32);
+extern template __global__ void lemsm::k_convert_points<Field29<Fr29Params>>(const uint4*, uint4*, u32);
+namespace {
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -52,7 +67,7 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0;
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   std::map<u64, DevBuf> pyr_cache;   // task tables keyed by (nb, gw)
 };
@@ -239,7 +254,7 @@ struct GroupWs {
 
 const u32 L2_RECORDS = 8;
 
-GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t ntasks_total) {
+GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t ntasks_total, size_t ptb) {
   GroupWs w; size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   u32 NBpad = pl.nbins << pl.LB;
@@ -247,8 +262,8 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t z0 = off;
   size_t o_bin_total = take(MAX_BINS * 4), o_bin_cursor = take(MAX_BINS * 4);
   size_t o_bcount = take((size_t)NBpad * 4), o_bcursor = take((size_t)NBpad * 4);
-  size_t o_arena = take((size_t)ar.total_points * 128);
-  size_t zend = o_arena + (size_t)NBpad * 128;   // only the bucket sums need zeroing
+  size_t o_arena = take((size_t)ar.total_points * ptb);
+  size_t zend = o_arena + (size_t)NBpad * ptb;   // only the bucket sums need zeroing
   size_t o_bin_start = take((MAX_BINS + 1) * 4), o_tile_prefix = take((MAX_BINS + 1) * 4), o_meta = take(64);
   size_t o_bstart = take(((size_t)NBpad + 1) * 4);
   size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 4);
@@ -256,7 +271,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t o_entries = take(Mmax * 4 + 16), o_sorted = take(Mmax * 4 + 16);
   size_t R1 = 2 * (size_t)pl.nthr1;
   size_t R2 = 2 * ((R1 + L2_RECORDS - 1) / L2_RECORDS);
-  size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * 128 + 128), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * 128 + 128);
+  size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * ptb + 256), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * ptb + 256);
   size_t o_tasks = take(ntasks_total * sizeof(PyrTask) + 64), o_copy = take(sizeof(CopyTask) + 64);
   w.total = off;
   if (base) {
@@ -315,7 +330,7 @@ u32 max_group_windows(u32 nb) {
 // are left in the arena's out area and copied to d_out (device) + gslot.
 template <class G, class Src>
 int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
-              char* ws_base, char* d_out /* device, gw*(L+1)*128 bytes */, bool time_it) {
+              char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, bool time_it) {
   hipStream_t st = ctx->stream;
   u32 gw = pl.w1 - pl.w0;
   u32 NBpad = pl.nbins << pl.LB;
@@ -323,7 +338,8 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
   PyrPlan pp = make_pyr_plan(ar, pl.nb, nbp, L);
   size_t ntasks_total = 0;
   for (auto& s : pp.steps) ntasks_total += s.size();
-  GroupWs w = carve(ws_base, pl, ar, ntasks_total);
+  const size_t ptb = G::PT_BYTES;
+  GroupWs w = carve(ws_base, pl, ar, ntasks_total, ptb);
 
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
   // upload task tables (small; pageable memcpy is synchronous w.r.t. host, fine)
@@ -344,8 +360,19 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
                      w.bucket_start, w.bucket_cursor, w.sorted);
 
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
-  hipLaunchKernelGGL((k_accum1<G>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, w.sorted, w.bucket_start, w.meta,
-                     (const uint4*)d_points, w.arena + (size_t)ar.bucket_off * 128, w.rec_key_a, w.rec_pt_a);
+  {
+    dim3 grid((pl.nthr1 + 255) / 256), blk(256);
+    char* bsum = w.arena + (size_t)ar.bucket_off * ptb;
+    // register-budget variant of the accumulate kernel (lazy field: 2, 3 or 4 waves per SIMD)
+    int wps = G::CONVERTED_DOMAIN ? (ctx->opt_accum_waves ? (int)ctx->opt_accum_waves : 3) : 4;
+    if constexpr (G::CONVERTED_DOMAIN) {
+      if (wps == 2) hipLaunchKernelGGL((k_accum1<G, 2>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      else if (wps == 4) hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      else hipLaunchKernelGGL((k_accum1<G, 3>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+    } else {
+      hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+    }
+  }
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
 
   // edge-record levels
@@ -355,7 +382,7 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
     for (;;) {
       u32 nthr = (R + L2_RECORDS - 1) / L2_RECORDS;
       hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, L2_RECORDS, ik, ip,
-                         w.arena + (size_t)ar.bucket_off * 128, ok, op);
+                         w.arena + (size_t)ar.bucket_off * ptb, ok, op);
       if (nthr == 1) break;
       R = 2 * nthr;
       std::swap(ik, ok); std::swap(ip, op);
@@ -371,30 +398,81 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
       hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, w.tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
       toff += tasks.size();
     }
-    u32 cthreads = gw * 8;
-    hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, w.copy_task, 1u, gw, w.arena);
+    u32 cthreads = gw * (u32)(ptb / 16);
+    hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, w.copy_task, 1u, gw, (u32)ptb, w.arena);
   }
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(d_out, w.arena + (size_t)ar.out_off * 128, (size_t)gw * (L + 1) * 128, hipMemcpyDeviceToDevice, st));
+  HIPCHK(ctx, hipMemcpyAsync(d_out, w.arena + (size_t)ar.out_off * ptb, (size_t)gw * (L + 1) * ptb, hipMemcpyDeviceToDevice, st));
   return LEMSM_OK;
 }
 
-size_t group_ws_bytes(const GroupPlan& pl, u32 nbp, u32 L) {
+size_t group_ws_bytes(const GroupPlan& pl, u32 nbp, u32 L, size_t ptb) {
   u32 gw = pl.w1 - pl.w0;
   ArenaLayout ar = make_arena(pl.nbins << pl.LB, nbp, gw, L);
   size_t ntasks = (size_t)(L + 2) * (L + 2);
-  GroupWs w = carve(nullptr, pl, ar, ntasks);
+  GroupWs w = carve(nullptr, pl, ar, ntasks, ptb);
   return w.total + 4096;
 }
 
 // Generic windowed bucket pipeline over window range [wb,we): fills host_out with
 // (we-wb) x (L+1) XYZZ points, summed over slabs.
-// multiply every coordinate by 2^-5: records of the lazy path are x*2^261, the host works on x*2^256
+// Device records -> host XYZZ points (x*2^256 Montgomery, canonical).
+// strict arithmetic: records already are 4 x 32-byte canonical x*2^256 values.
+// lazy arithmetic: records are 36 raw signed 29-bit limbs of x*2^261 representatives with
+// |V| < 8N: add 8N, carry-normalise, reduce mod N, then multiply by 2^-5 (montmul by 2^251).
 template <class P64>
-void from_converted_domain(std::vector<host::pt>& v) {
+host::fe reduce_raw29(const int32_t* l) {
   typedef host::HF<P64> F;
+  // N as 29-bit limbs
+  int64_t v[9];
+  u64 n29[9];
+  for (int i = 0; i < 9; i++) {
+    int bit = 29 * i, wi = bit >> 6, sh = bit & 63;
+    u64 lo = P64::N[wi] >> sh;
+    u64 hi = (sh + 29 > 64 && wi + 1 < 4) ? (P64::N[wi + 1] << (64 - sh)) : 0;
+    n29[i] = (lo | hi) & ((1ULL << 29) - 1);
+  }
+  int64_t c = 0;
+  for (int i = 0; i < 9; i++) {
+    int64_t t = (int64_t)l[i] + (int64_t)(n29[i] << 3) + c;   // + 8N limb-wise (limbs may exceed 29 bits; carried below)
+    if (i < 8) { v[i] = t & ((1LL << 29) - 1); c = t >> 29; } else v[i] = t;
+  }
+  // pack the non-negative value (< 16N < 2^258) into 5 x u64
+  u64 w[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 9; i++) {   // limbs are disjoint bit fields now: OR them in
+    int bit = 29 * i, wi = bit >> 6, sh = bit & 63;
+    w[wi] |= (u64)v[i] << sh;
+    if (sh + 29 > 64 && wi + 1 < 5) w[wi + 1] |= (u64)v[i] >> (64 - sh);
+  }
+  // reduce below N by subtracting N while >= N (at most 16 times)
+  for (int it = 0; it < 20; it++) {
+    bool ge = w[4] != 0;
+    if (!ge) { ge = true; for (int i = 3; i >= 0; i--) { if (w[i] > P64::N[i]) break; if (w[i] < P64::N[i]) { ge = false; break; } } }
+    if (!ge) break;
+    u64 bw = 0;
+    for (int i = 0; i < 5; i++) { unsigned __int128 d = (unsigned __int128)w[i] - (i < 4 ? P64::N[i] : 0) - bw; w[i] = (u64)d; bw = (u64)(d >> 64) & 1; }
+  }
+  host::fe r; for (int i = 0; i < 4; i++) r.l[i] = w[i];
   host::fe k251 = {{0, 0, 0, 0x0800000000000000ULL}};   // 2^251 (< N): montmul(a, 2^251) = a * 2^-5
-  for (auto& p : v) { p.x = F::mul(p.x, k251); p.y = F::mul(p.y, k251); p.zz = F::mul(p.zz, k251); p.zzz = F::mul(p.zzz, k251); }
+  return F::mul(r, k251);
+}
+
+template <class P64, class G>
+void from_device_records(const std::vector<char>& raw, std::vector<host::pt>& out) {
+  size_t n = raw.size() / G::PT_BYTES;
+  out.resize(n);
+  if constexpr (!G::CONVERTED_DOMAIN) {
+    memcpy(out.data(), raw.data(), n * sizeof(host::pt));
+  } else {
+    for (size_t i = 0; i < n; i++) {
+      const int32_t* l = reinterpret_cast<const int32_t*>(raw.data() + i * G::PT_BYTES);
+      bool zz_zero = true;
+      for (int k = 0; k < 9; k++) zz_zero &= (l[18 + k] == 0);
+      if (zz_zero) { memset(&out[i], 0, sizeof(host::pt)); continue; }
+      out[i].x = reduce_raw29<P64>(l); out[i].y = reduce_raw29<P64>(l + 9);
+      out[i].zz = reduce_raw29<P64>(l + 18); out[i].zzz = reduce_raw29<P64>(l + 27);
+    }
+  }
 }
 
 template <class P64, class G, class MakeSrc>
@@ -413,18 +491,20 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     u32 sn = (u32)std::min(SLAB, n - s0);
     for (u32 g0 = wb; g0 < we; g0 += gmax) {
       GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, g0, std::min(we, g0 + gmax), d);
-      need = std::max(need, group_ws_bytes(pl, nbp, L));
+      need = std::max(need, group_ws_bytes(pl, nbp, L, G::PT_BYTES));
     }
   }
   need = align_up(need, 256);
-  size_t out_bytes = align_up((size_t)nw * (L + 1) * 128, 256);
+  const size_t ptb = G::PT_BYTES;
+  size_t out_bytes = align_up((size_t)nw * (L + 1) * ptb, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
   int rc = reserve(ctx, ctx->ws, need + out_bytes + conv_bytes + 4096);
   if (rc) return rc;
   char* ws_base = (char*)ctx->ws.p;
   char* d_out = ws_base + need;
   char* d_conv = d_out + out_bytes;
-  std::vector<host::pt> tmp((size_t)nw * (L + 1));
+  std::vector<host::pt> tmp;
+  std::vector<char> raw((size_t)nw * (L + 1) * ptb);
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
   for (size_t s0 = 0; s0 < n; s0 += SLAB) {
@@ -438,15 +518,15 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
       u32 g1 = std::min(we, g0 + gmax);
       GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, g0, g1, d);
       auto src = make_src(s0, sn);
-      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base, d_out + (size_t)(g0 - wb) * (L + 1) * 128, true);
+      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base, d_out + (size_t)(g0 - wb) * (L + 1) * ptb, true);
       if (rc) return rc;
       HIPCHK(ctx, hipStreamSynchronize(st));
       float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
       ctx->t_accum_ms += ms; ctx->n_accum++;
     }
-    HIPCHK(ctx, hipMemcpyAsync(tmp.data(), d_out, (size_t)nw * (L + 1) * 128, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if constexpr (G::CONVERTED_DOMAIN) from_converted_domain<P64>(tmp);
+    from_device_records<P64, G>(raw, tmp);
     if (s0 == 0) host_out = tmp;
     else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = HGp::add(host_out[i], tmp[i]);
   }
@@ -711,6 +791,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return LEMSM_ERR_BAD_ARG; ctx->opt_window_bits = value; }
   else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
+  else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }
   else if (!strcmp(name, "field")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_field = value; }
   else return LEMSM_ERR_BAD_ARG;
   return LEMSM_OK;

@@ -124,6 +124,7 @@ struct XYZZ {
   static __device__ __forceinline__ void neg(pt& p) { F::neg(p.y, p.y); }
 
   // memory format of an XYZZ point: 4 x 32 bytes (x, y, zz, zzz), raw Montgomery limbs
+  static constexpr u32 PT_BYTES = 128;
   static __device__ __forceinline__ void load(pt& p, const void* mem) {
     const char* m = reinterpret_cast<const char*>(mem);
     F::load(p.x, m); F::load(p.y, m + 32); F::load(p.zz, m + 64); F::load(p.zzz, m + 96);

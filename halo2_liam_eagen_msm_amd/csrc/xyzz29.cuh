@@ -9,8 +9,7 @@
 // A mixed addition is 7 multiplications + 2 squarings worth of products and 9 reductions
 // (~2,000 VALU instructions).
 //
-// Points in memory: 4 x 32 bytes (x, y, zz, zzz), canonical integers of the 2^261-domain
-// residues; identity = all zero (zz == 0).
+// Points in memory: 160 bytes of raw limbs (see load/store below); identity = all zero.
 #pragma once
 #include "field29.cuh"
 
@@ -62,7 +61,7 @@ struct XYZZ29 {
     // X3 = M^2 - 2S :  hi = 2N - 0 - 2S
     fe zero; F::set_zero(zero);
     hi_term(t, zero, S);
-    F::mul_addhi(x3, M, M, t);
+    F::sqr_addhi(x3, M, t);
     // Y3 = M*(S - X3) - W*Y
     F::sub(t, S, x3); F::neg(nW, W);
     fe y = p.y; F::wnorm(y);
@@ -97,7 +96,7 @@ struct XYZZ29 {
     F::mul(Q, acc.x, PP);
     hi_term(t, PPP, Q);
     F::neg(nY, acc.y);
-    F::mul_addhi(acc.x, R, R, t);                  // X3 = R^2 - PPP - 2Q
+    F::sqr_addhi(acc.x, R, t);                     // X3 = R^2 - PPP - 2Q
     F::sub(t, Q, acc.x);
     F::mul2(acc.y, R, t, nY, PPP);                 // Y3 = R(Q - X3) - Y1*PPP
     F::mul(acc.zz, acc.zz, PP);
@@ -126,27 +125,35 @@ struct XYZZ29 {
     F::mul(Q, U1, PP);
     hi_term(t, PPP, Q);
     F::neg(nS, S1);
-    F::mul_addhi(acc.x, R, R, t);
+    F::sqr_addhi(acc.x, R, t);
     F::sub(t, Q, acc.x);
     F::mul2(acc.y, R, t, nS, PPP);
     F::mul(t, acc.zz, q.zz); F::mul(acc.zz, t, PP);
     F::mul(t, acc.zzz, q.zzz); F::mul(acc.zzz, t, PPP);
   }
 
+  // Memory format of a point of this arithmetic: the 36 raw limbs (x, y, zz, zzz; 9 x i32 each)
+  // + 4 pad words = 160 bytes, NOT canonicalised: storing is ten 16-byte stores.  (Canonical
+  // packing costs ~900 instructions per point and the flush branch of k_accum1 is taken by some
+  // lane in a third of all iterations.)  The host reduces the few hundred result points
+  // (lemsm.hip: from_device_records).  Identity = all zero.
+  static constexpr u32 PT_BYTES = 160;
   static __device__ __forceinline__ void load(pt& p, const void* mem) {
-    const char* m = reinterpret_cast<const char*>(mem);
-    F::load(p.x, m); F::load(p.y, m + 32); F::load(p.zz, m + 64); F::load(p.zzz, m + 96);
+    const uint4* q = reinterpret_cast<const uint4*>(mem);
+    u32 w[40];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { p.x.l[i] = (i32)w[i]; p.y.l[i] = (i32)w[9 + i]; p.zz.l[i] = (i32)w[18 + i]; p.zzz.l[i] = (i32)w[27 + i]; }
   }
   static __device__ __forceinline__ void store(void* mem, const pt& p) {
-    char* m = reinterpret_cast<char*>(mem);
-    if (is_identity(p)) {
-      uint4 z = make_uint4(0, 0, 0, 0);
-      uint4* q = reinterpret_cast<uint4*>(m);
+    uint4* q = reinterpret_cast<uint4*>(mem);
+    u32 w[40];
 #pragma unroll
-      for (int i = 0; i < 8; i++) q[i] = z;
-      return;
-    }
-    F::store(m, p.x); F::store(m + 32, p.y); F::store(m + 64, p.zz); F::store(m + 96, p.zzz);
+    for (int i = 0; i < 9; i++) { w[i] = (u32)p.x.l[i]; w[9 + i] = (u32)p.y.l[i]; w[18 + i] = (u32)p.zz.l[i]; w[27 + i] = (u32)p.zzz.l[i]; }
+    w[36] = w[37] = w[38] = w[39] = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
   }
 };
 
