@@ -1,0 +1,98 @@
+"""Host-side logic of the product library, runnable without a GPU: digit counts, plans, the
+Horner tails (lemsm_msm_combine / lemsm_lhs_combine) fed with oracle-built window records, and
+canonicalisation.  No device entry point is called."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import hostref
+from helpers import CURVES, canon
+from halo2_liam_eagen_msm_amd import _lib, api
+from oracle import cref, pyref
+
+
+def test_num_digits_matches_reference_formula():
+    for c in CURVES:
+        for base in (3, 4, 5, 7, 16, 17, 255):
+            assert api.num_digits(c.cid, base) == pyref.num_digits(c.order, base)
+    with pytest.raises(api.BadBase):
+        api.num_digits(0, 1)
+
+
+def test_scalar_helpers_mirror_reference():
+    assert api.logb_ceil(0, 5) == 0 and api.logb_ceil(24, 5) == 2 and api.logb_ceil(25, 5) == 3
+    assert api.id_by_digit(0) is None and api.id_by_digit(7) == 6 and api.digit_by_id(6) == 7
+    assert api.order("bn254_g1") == pyref.R_BN254 and api.order("grumpkin") == pyref.P_BN254
+
+
+def test_msm_plan_windows():
+    for c in CURVES:
+        for n in (1, 100, 1 << 12, 1 << 20, 1 << 24, 1 << 26):
+            W, L, rec = hostref.msm_plan(c, n)
+            cbits = L + 1
+            assert rec == (L + 1) * 128 and 3 <= cbits <= 16
+            K = sum((1 << (cbits - 1)) << (cbits * w) for w in range(W - 1))
+            assert ((c.order - 1 + K) >> (cbits * (W - 1))) <= (1 << (cbits - 1))   # top window fits the buckets
+            assert (c.order - 1 + K) >> (cbits * W) == 0
+        assert hostref.msm_plan(c, 1 << 24)[0] == 16    # 16-bit windows: 16 windows, 8/4/2 per rank on 2/4/8 GPUs
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 7, 40, 300])
+def test_msm_combine_with_oracle_records(curve, n):
+    rng = pyref.SplitMix64(900 + n)
+    pts = pyref.gen_points(curve, rng, min(n, 12)) * (n // 12 + 1)
+    pts = pts[:n]
+    sc = pyref.gen_scalars_full(rng, n, curve.order)
+    sc[0] = curve.order - 1
+    W, rec, recs = hostref.msm_records(curve, sc, pts)
+    out = hostref.msm_combine(curve, n, b"".join(recs))
+    assert canon(curve, out) == curve.canonical(curve.msm_naive(sc, pts))
+    assert api.jacobian_to_canonical(curve.cid, out) == canon(curve, out)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("base", [3, 5, 16, 255])
+def test_lhs_combine_with_oracle_records(curve, base):
+    n = 25
+    rng = pyref.SplitMix64(950 + base)
+    pts = pyref.gen_points(curve, rng, n)
+    sc = pyref.gen_scalars_half(rng, n, curve.order)
+    d, rec, recs = hostref.lhs_records(curve, sc, pts, base)
+    carry, carries = hostref.lhs_combine(curve, base, b"".join(recs))
+    ecarry, ecarries = pyref.lhs_msm(curve, sc, pts, base)
+    assert canon(curve, carry) == curve.canonical(ecarry)
+    for i in range(d):
+        assert canon(curve, carries[i]) == curve.canonical(ecarries[i]), i
+
+
+def test_jacobian_to_canonical_identity_and_scaling():
+    c = pyref.GRUMPKIN
+    assert api.jacobian_to_canonical(c.cid, np.zeros(12, np.uint64)) == bytes(64)
+    pt = c.mul(12345, c.gen)
+    for z in (1, 2, 0xABCDEF):
+        j = np.frombuffer(c.affine_to_jacobian_raw(pt, z), np.uint64)
+        assert api.jacobian_to_canonical(c.cid, j) == c.canonical(pt)
+
+
+def test_status_strings_and_bad_args():
+    lib = _lib.load()
+    assert lib.lemsm_strerror(1) == b"incompatible amount of coefficients"
+    assert lib.lemsm_strerror(2) == b"scalar out of range"
+    d = ctypes.c_uint32()
+    assert lib.lemsm_num_digits(7, 5, ctypes.byref(d)) == _lib.LEMSM_ERR_BAD_CURVE
+    assert lib.lemsm_lhs_plan(0, 2, None, None) == _lib.LEMSM_ERR_BAD_BASE
+
+
+def test_product_fails_loudly_without_gpu():
+    """no CPU fallback: without a usable gfx950 device context creation raises"""
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    rc = lib.lemsm_create(0, ctypes.byref(h))
+    if rc == 0:          # running on a GPU box
+        lib.lemsm_destroy(h)
+    else:
+        assert rc == _lib.LEMSM_ERR_HIP
+        with pytest.raises(api.LemsmError):
+            api.Context(0)
