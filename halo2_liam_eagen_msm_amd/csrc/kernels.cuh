@@ -8,17 +8,17 @@
 //
 // Reference behaviour being replaced (paths relative to /root/reference):
 //   src/negbase_utils.rs:20-36        negbase_decompose         -> k_negbase_digits
-//   src/negbase_utils.rs:46-51        id_by_digit (bucket = digit-1, 0 skipped) -> NegSrc
+//   src/negbase_utils.rs:46-51        id_by_digit (bucket = digit-1, 0 skipped) -> NegDec
 //   src/argument_witness_calc.rs:97   scalar range assert       -> k_negbase_digits (flag)
 //   src/argument_witness_calc.rs:105-127 per-digit sums S_i of the Horner recursion -> buckets
-//   halo2 best_multiexp (third party) bucket accumulation       -> PipSrc + same kernels
+//   halo2 best_multiexp (third party) bucket accumulation       -> k_pip_digits/PipDec + same kernels
 #pragma once
 #include "kernels_ec.cuh"
 
 namespace lemsm {
 
 // ------------------------------------------------------------------------------------
-// digit sources
+// window digit matrices and their decoders
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 extract_bits(const u32 (&s)[8], u32 bitpos, u32 c) {
   u32 li = bitpos >> 5, sh = bitpos & 31;
@@ -32,65 +32,94 @@ __device__ __forceinline__ u32 extract_bits(const u32 (&s)[8], u32 bitpos, u32 c
   return (u32)(v >> sh) & ((1u << c) - 1u);
 }
 
-// Signed-window Pippenger digits: s' = s + K with K = sum_{w<W-1} 2^(c-1) 2^(cw); digit_w =
-// win_w(s') - 2^(c-1) for w < W-1, top window unsigned (host guarantees it fits nb buckets).
-struct PipSrc {
-  const uint4* scalars;   // n x 32 B canonical little-endian (== PrimeField::to_repr())
-  u32 kadd[8];
-  template <class Fn>
-  __device__ __forceinline__ void for_each_digit(u32 j, const GroupPlan& pl, Fn f) const {
-    uint4 a = scalars[2 * (size_t)j], b = scalars[2 * (size_t)j + 1];
-    u32 s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    u32 cy = 0;
+struct KAdd { u32 k[8]; };
+
+// Signed-window Pippenger: s' = s + K with K = sum_{w<W-1} 2^(c-1) 2^(cw).  The raw c-bit windows
+// of s' are written window-major (dig16[(w-w0)*n + j], one coalesced 2-byte column per window) so
+// that the sort passes stream one window at a time.
+__global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ scalars, KAdd kadd, GroupPlan pl,
+                                                    uint16_t* __restrict__ dig16) {
+  u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= pl.n) return;
+  uint4 a = scalars[2 * (size_t)j], b = scalars[2 * (size_t)j + 1];
+  u32 s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32 cy = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = __builtin_addc(s[i], kadd[i], cy, &cy);
+  for (int i = 0; i < 8; i++) s[i] = __builtin_addc(s[i], kadd.k[i], cy, &cy);
+  for (u32 w = pl.w0; w < pl.w1; w++)
+    dig16[(size_t)(w - pl.w0) * pl.n + j] = (uint16_t)extract_bits(s, w * pl.c, pl.c);
+}
+
+// decoders: bucket (0 = skip) and sign of scalar j in window w
+struct PipDec {
+  const uint16_t* dig16;
+  __device__ __forceinline__ void get(u32 j, u32 w, const GroupPlan& pl, u32& bucket, u32& sign) const {
+    u32 raw = dig16[(size_t)(w - pl.w0) * pl.n + j];
     const u32 half = 1u << (pl.c - 1);
-    for (u32 w = pl.w0; w < pl.w1; w++) {
-      u32 raw = extract_bits(s, w * pl.c, pl.c);
-      u32 bucket, sign;
-      if (w + 1 < pl.W) {
-        sign = raw < half ? 1u : 0u;
-        bucket = sign ? half - raw : raw - half;
-      } else {
-        sign = 0; bucket = raw;
-      }
-      if (bucket) f((w - pl.w0) * pl.nb + bucket - 1u, sign);
-    }
+    if (w + 1 < pl.W) {          // digit = raw - 2^(c-1), top window unsigned
+      sign = raw < half ? 1u : 0u;
+      bucket = sign ? half - raw : raw - half;
+    } else { sign = 0; bucket = raw; }
   }
 };
-
-// Negabase digits, position-major matrix digitsT[pos][j]; bucket id = digit-1
-// (id_by_digit, src/negbase_utils.rs:46-51), digit 0 skipped.
-struct NegSrc {
+// negabase digit matrix, position-major; bucket id = digit (id_by_digit: digit-1, 0 skipped;
+// src/negbase_utils.rs:46-51)
+struct NegDec {
   const uint8_t* digitsT;   // d x n
-  template <class Fn>
-  __device__ __forceinline__ void for_each_digit(u32 j, const GroupPlan& pl, Fn f) const {
-    for (u32 w = pl.w0; w < pl.w1; w++) {
-      u32 dg = digitsT[(size_t)w * pl.n + j];
-      if (dg) f((w - pl.w0) * pl.nb + dg - 1u, 0u);
-    }
+  __device__ __forceinline__ void get(u32 j, u32 w, const GroupPlan& pl, u32& bucket, u32& sign) const {
+    bucket = digitsT[(size_t)w * pl.n + j]; sign = 0;
   }
 };
 
+// exclusive scan of one value per thread across a 256-thread block
+__device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* total, u32* wsum /* >= 4 words LDS */) {
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    u32 y = __shfl_up(x, o);
+    if (lane >= (u32)o) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+#pragma unroll
+  for (u32 w = 0; w < 4; w++) {
+    u32 s = wsum[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
 // ------------------------------------------------------------------------------------
-// pass 1: partition (key, point index) pairs by coarse bin
+// pass 1: partition (bucket, point index) pairs by coarse bin.  One block = one window x one
+// range of <= STAGE scalars.  Keys: key = (w-w0)*nbw + bucket-1, bin = key >> LB, BW bins per window.
+// The scatter stages a block's entries bin-sorted in LDS and writes each (block, bin) run with
+// consecutive lanes on consecutive addresses: scattered 4-byte stores cost ~16x write
+// amplification in HBM (the first version of this pass ran at 0.5 TB/s).
 // ------------------------------------------------------------------------------------
-template <class Src>
-__global__ __launch_bounds__(256) void k_count1(Src src, GroupPlan pl, u32* __restrict__ block_counts,
+static const u32 STAGE = 8192;
+
+template <class Dec>
+__global__ __launch_bounds__(256) void k_count1(Dec dec, GroupPlan pl, u32* __restrict__ block_counts,
                                                 u32* __restrict__ bin_total) {
-  __shared__ u32 hist[MAX_BINS];
-  const u32 tid = threadIdx.x;
-  for (u32 i = tid; i < pl.nbins; i += 256) hist[i] = 0;
+  __shared__ u32 hist[256];
+  const u32 tid = threadIdx.x, r = blockIdx.x, wl = blockIdx.y, w = pl.w0 + wl;
+  hist[tid] = 0;
   __syncthreads();
-  u32 j0 = blockIdx.x * pl.spb;
-  u32 j1 = min(j0 + pl.spb, pl.n);
-  for (u32 j = j0 + tid; j < j1; j += 256)
-    src.for_each_digit(j, pl, [&](u32 key, u32) { atomicAdd(&hist[key >> pl.LB], 1u); });
+  u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
+  for (u32 j = j0 + tid; j < j1; j += 256) {
+    u32 bucket, sign; dec.get(j, w, pl, bucket, sign);
+    if (bucket) atomicAdd(&hist[(bucket - 1u) >> pl.LB], 1u);
+  }
   __syncthreads();
-  for (u32 i = tid; i < pl.nbins; i += 256) {
-    u32 cnt = hist[i];
-    block_counts[(size_t)blockIdx.x * pl.nbins + i] = cnt;
-    if (cnt) atomicAdd(&bin_total[i], cnt);
+  if (tid < pl.BW) {
+    u32 cnt = hist[tid];
+    block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + tid] = cnt;
+    if (cnt) atomicAdd(&bin_total[wl * pl.BW + tid], cnt);
   }
 }
 
@@ -145,32 +174,45 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
   }
 }
 
-template <class Src>
-__global__ __launch_bounds__(256) void k_scatter1(Src src, GroupPlan pl, const u32* __restrict__ block_counts,
+template <class Dec>
+__global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
                                                   const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
                                                   u32* __restrict__ entries) {
-  __shared__ u32 base[MAX_BINS];
-  __shared__ u32 lcur[MAX_BINS];
-  const u32 tid = threadIdx.x;
-  for (u32 i = tid; i < pl.nbins; i += 256) {
-    u32 cnt = block_counts[(size_t)blockIdx.x * pl.nbins + i];
-    base[i] = cnt ? bin_start[i] + atomicAdd(&bin_cursor[i], cnt) : 0u;
-    lcur[i] = 0;
-  }
+  __shared__ u32 lstart[257];
+  __shared__ u32 gbase[256];
+  __shared__ u32 lcur[256];
+  __shared__ u32 wsum[4];
+  __shared__ u32 stage[STAGE];
+  __shared__ uint8_t sbin[STAGE];
+  const u32 tid = threadIdx.x, r = blockIdx.x, wl = blockIdx.y, w = pl.w0 + wl;
+  u32 cnt = tid < pl.BW ? block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + tid] : 0u;
+  u32 total;
+  u32 off = block_excl_scan_256(cnt, &total, wsum);
+  lstart[tid] = off;
+  if (tid == 255) lstart[256] = total;
+  gbase[tid] = cnt ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt) : 0u;
+  lcur[tid] = 0;
   __syncthreads();
   const u32 lmask = (1u << pl.LB) - 1u;
-  u32 j0 = blockIdx.x * pl.spb;
-  u32 j1 = min(j0 + pl.spb, pl.n);
-  for (u32 j = j0 + tid; j < j1; j += 256)
-    src.for_each_digit(j, pl, [&](u32 key, u32 sign) {
-      u32 bin = key >> pl.LB;
-      u32 pos = base[bin] + atomicAdd(&lcur[bin], 1u);
-      entries[pos] = j | ((key & lmask) << 24) | (sign << 31);
-    });
+  u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
+  for (u32 j = j0 + tid; j < j1; j += 256) {
+    u32 bucket, sign; dec.get(j, w, pl, bucket, sign);
+    if (bucket) {
+      u32 k = bucket - 1u, b = k >> pl.LB;
+      u32 q = lstart[b] + atomicAdd(&lcur[b], 1u);
+      stage[q] = j | ((k & lmask) << 24) | (sign << 31);
+      sbin[q] = (uint8_t)b;
+    }
+  }
+  __syncthreads();
+  for (u32 q = tid; q < total; q += 256) {
+    u32 b = sbin[q];
+    entries[gbase[b] + (q - lstart[b])] = stage[q];
+  }
 }
 
 // ------------------------------------------------------------------------------------
-// pass 2: exact bucket sort inside each bin, one tile (<= T2 entries of one bin) per block
+// pass 2: exact bucket sort inside each bin, one tile (<= T2 <= STAGE entries of one bin) per block
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ bool locate_tile(const GroupPlan& pl, const u32* __restrict__ bin_start,
                                             const u32* __restrict__ tile_prefix, const u32* __restrict__ meta,
@@ -225,28 +267,39 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
                                                   const u32* __restrict__ bin_start, const u32* __restrict__ tile_prefix,
                                                   const u32* __restrict__ meta, const u32* __restrict__ bucket_start,
                                                   u32* __restrict__ bucket_cursor, u32* __restrict__ sorted) {
-  __shared__ u32 hist[1u << MAX_LB];
-  __shared__ u32 base[1u << MAX_LB];
+  __shared__ u32 hist[256];
+  __shared__ u32 lstart[257];
+  __shared__ u32 gbase[256];
+  __shared__ u32 wsum[4];
+  __shared__ u32 stage[STAGE];
+  __shared__ uint8_t sloc[STAGE];
   u32 bin, off, end;
   if (!locate_tile(pl, bin_start, tile_prefix, meta, bin, off, end)) return;
   const u32 tid = threadIdx.x;
-  if (tid < (1u << MAX_LB)) hist[tid] = 0;
+  hist[tid] = 0;
   __syncthreads();
   for (u32 i = off + tid; i < end; i += 256) atomicAdd(&hist[(entries[i] >> 24) & 127u], 1u);
   __syncthreads();
-  if (tid < (1u << MAX_LB)) {
-    u32 cnt = tid < (1u << pl.LB) ? hist[tid] : 0u;
-    u32 key = (bin << pl.LB) + tid;
-    base[tid] = cnt ? bucket_start[key] + atomicAdd(&bucket_cursor[key], cnt) : 0u;
-  }
-  __syncthreads();
-  if (tid < (1u << MAX_LB)) hist[tid] = 0;
+  u32 cnt = tid < (1u << pl.LB) ? hist[tid] : 0u;
+  u32 total;
+  u32 o = block_excl_scan_256(cnt, &total, wsum);
+  lstart[tid] = o;
+  if (tid == 255) lstart[256] = total;
+  u32 key = (bin << pl.LB) + tid;
+  gbase[tid] = cnt ? bucket_start[key] + atomicAdd(&bucket_cursor[key], cnt) : 0u;
+  hist[tid] = 0;
   __syncthreads();
   for (u32 i = off + tid; i < end; i += 256) {
     u32 e = entries[i];
     u32 l = (e >> 24) & 127u;
-    u32 pos = base[l] + atomicAdd(&hist[l], 1u);
-    sorted[pos] = e & 0x80ffffffu;
+    u32 q = lstart[l] + atomicAdd(&hist[l], 1u);
+    stage[q] = e & 0x80ffffffu;
+    sloc[q] = (uint8_t)l;
+  }
+  __syncthreads();
+  for (u32 q = tid; q < total; q += 256) {
+    u32 l = sloc[q];
+    sorted[gbase[l] + (q - lstart[l])] = stage[q];
   }
 }
 

@@ -196,12 +196,12 @@ ArenaLayout make_arena(u32 NBpad, u32 nbp, u32 gw, u32 L) {
   return a;
 }
 
-PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbp, u32 L) {
+PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbw, u32 nbp, u32 L) {
   PyrPlan pp;
   auto offA = [&](u32 l) { return nbp - (nbp >> (l - 1)); };                    // level l >= 1 inside a window's A region
   auto offR = [&](u32 l, u32 j) { u32 rs = nbp >> (l + 1); return (nbp - (nbp >> l)) + (rs - (rs >> (j - 1))); };
   auto srcA = [&](u32 l, PyrTask& t) {    // A^l as a source
-    if (l == 0) { t.src_off = ar.bucket_off; t.src_wstride = nb; t.src_valid = nb; }
+    if (l == 0) { t.src_off = ar.bucket_off; t.src_wstride = nbw; t.src_valid = nb; }
     else { t.src_off = ar.apyr_off + offA(l); t.src_wstride = nbp; t.src_valid = nbp >> l; }
   };
   for (u32 s = 1; s <= L; s++) {
@@ -230,7 +230,7 @@ PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbp, u32 L) {
   }
   // U_{L-1} = A^{L-1}[1]
   memset(&pp.copy, 0, sizeof pp.copy);
-  if (L == 1) { pp.copy.src_off = ar.bucket_off; pp.copy.src_wstride = nb; pp.copy.src_valid_idx = nb; }
+  if (L == 1) { pp.copy.src_off = ar.bucket_off; pp.copy.src_wstride = nbw; pp.copy.src_valid_idx = nb; }
   else { pp.copy.src_off = ar.apyr_off + offA(L - 1); pp.copy.src_wstride = nbp; pp.copy.src_valid_idx = 2; }
   pp.copy.src_idx = 1;
   pp.copy.dst_off = ar.out_off + L; pp.copy.dst_wstride = L + 1;
@@ -245,6 +245,7 @@ struct GroupWs {
   u32* bin_total; u32* bin_cursor; u32* bin_start; u32* tile_prefix; u32* meta;
   u32* bucket_count; u32* bucket_cursor; u32* bucket_start;
   u32* block_counts;
+  uint16_t* dig16;
   u32* entries; u32* sorted;
   u32* rec_key_a; char* rec_pt_a; u32* rec_key_b; char* rec_pt_b;
   PyrTask* tasks; CopyTask* copy_task;
@@ -267,6 +268,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t o_bin_start = take((MAX_BINS + 1) * 4), o_tile_prefix = take((MAX_BINS + 1) * 4), o_meta = take(64);
   size_t o_bstart = take(((size_t)NBpad + 1) * 4);
   size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 4);
+  size_t o_dig = take(pl.c ? (size_t)pl.n * (pl.w1 - pl.w0) * 2 + 16 : 16);
   size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
   size_t o_entries = take(Mmax * 4 + 16), o_sorted = take(Mmax * 4 + 16);
   size_t R1 = 2 * (size_t)pl.nthr1;
@@ -279,7 +281,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
     w.bucket_count = (u32*)(base + o_bcount); w.bucket_cursor = (u32*)(base + o_bcursor);
     w.arena = base + o_arena;
     w.bin_start = (u32*)(base + o_bin_start); w.tile_prefix = (u32*)(base + o_tile_prefix); w.meta = (u32*)(base + o_meta);
-    w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc);
+    w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc); w.dig16 = (uint16_t*)(base + o_dig);
     w.entries = (u32*)(base + o_entries); w.sorted = (u32*)(base + o_sorted);
     w.rec_key_a = (u32*)(base + o_rka); w.rec_pt_a = base + o_rpa; w.rec_key_b = (u32*)(base + o_rkb); w.rec_pt_b = base + o_rpb;
     w.tasks = (PyrTask*)(base + o_tasks); w.copy_task = (CopyTask*)(base + o_copy);
@@ -291,20 +293,22 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
 GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32 w0, u32 w1, u32 d) {
   GroupPlan g; memset(&g, 0, sizeof g);
   g.n = n; g.c = c; g.nb = nb; g.W = W; g.w0 = w0; g.w1 = w1; g.d = d;
-  g.NB = (w1 - w0) * nb;
   u32 LB = 0;
-  while (((g.NB + (1u << LB) - 1) >> LB) > MAX_BINS) LB++;
+  while (((nb + (1u << LB) - 1) >> LB) > 256) LB++;     // <= 256 coarse bins per window
   g.LB = LB;
-  g.nbins = (g.NB + (1u << LB) - 1) >> LB;
-  if (g.nbins == 0) g.nbins = 1;
+  g.BW = (nb + (1u << LB) - 1) >> LB;
+  g.nbw = g.BW << LB;
+  g.NB = (w1 - w0) * g.nbw;
+  g.nbins = (w1 - w0) * g.BW;
   u32 spb = (n + 1023) / 1024;
-  spb = std::max(256u, std::min(16384u, spb));
+  spb = std::max(256u, std::min((u32)STAGE, spb));
   spb = (spb + 255) / 256 * 256;
+  if (n >= (1u << 16)) spb = STAGE;     // long (block, bin) runs -> full-line writes
   g.spb = spb;
   g.nblk1 = (n + spb - 1) / spb;
   if (g.nblk1 == 0) g.nblk1 = 1;
   size_t Mmax = (size_t)n * (w1 - w0);
-  u32 T2 = ctx->opt_tile > 0 ? (u32)ctx->opt_tile : 16384u;
+  u32 T2 = ctx->opt_tile > 0 ? std::min((u32)ctx->opt_tile, (u32)STAGE) : (u32)STAGE;
   g.T2 = T2;
   g.max_tiles = (u32)(Mmax / T2) + g.nbins + 1;
   u32 L1;
@@ -320,22 +324,41 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   return g;
 }
 
-// max windows per group: NB_group <= MAX_BINS << MAX_LB
+// max windows per group: (w1-w0) * BW <= MAX_BINS
 u32 max_group_windows(u32 nb) {
-  u32 cap = (MAX_BINS << MAX_LB) / nb;
+  u32 LB = 0;
+  while (((nb + (1u << LB) - 1) >> LB) > 256) LB++;
+  u32 BW = (nb + (1u << LB) - 1) >> LB;
+  u32 cap = MAX_BINS / BW;
   return cap == 0 ? 1 : cap;
 }
 
+// digit providers: produce the decoder the sort passes read (bucket, sign) through
+struct PipProvider {
+  const uint4* scalars; KAdd kadd;
+  typedef PipDec Dec;
+  int prepare(lemsm_ctx* ctx, const GroupPlan& pl, uint16_t* dig16, Dec& dec) const {
+    hipLaunchKernelGGL(k_pip_digits, dim3((pl.n + 255) / 256), dim3(256), 0, ctx->stream, scalars, kadd, pl, dig16);
+    dec.dig16 = dig16;
+    return LEMSM_OK;
+  }
+};
+struct NegProvider {
+  const uint8_t* digitsT;
+  typedef NegDec Dec;
+  int prepare(lemsm_ctx*, const GroupPlan&, uint16_t*, Dec& dec) const { dec.digitsT = digitsT; return LEMSM_OK; }
+};
+
 // Runs one window group [w0,w1): sort + accumulate + reduce; results (gw x (L+1) XYZZ points)
 // are left in the arena's out area and copied to d_out (device) + gslot.
-template <class G, class Src>
-int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
+template <class G, class Prov>
+int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
               char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, bool time_it) {
   hipStream_t st = ctx->stream;
   u32 gw = pl.w1 - pl.w0;
   u32 NBpad = pl.nbins << pl.LB;
   ArenaLayout ar = make_arena(NBpad, nbp, gw, L);
-  PyrPlan pp = make_pyr_plan(ar, pl.nb, nbp, L);
+  PyrPlan pp = make_pyr_plan(ar, pl.nb, pl.nbw, nbp, L);
   size_t ntasks_total = 0;
   for (auto& s : pp.steps) ntasks_total += s.size();
   const size_t ptb = G::PT_BYTES;
@@ -351,9 +374,11 @@ int run_group(lemsm_ctx* ctx, const Src& src, const GroupPlan& pl, u32 nbp, u32 
     HIPCHK(ctx, hipStreamSynchronize(st));   // flat/pp are stack objects
   }
 
-  hipLaunchKernelGGL((k_count1<Src>), dim3(pl.nblk1), dim3(256), 0, st, src, pl, w.block_counts, w.bin_total);
+  typename Prov::Dec dec;
+  { int rcp = prov.prepare(ctx, pl, w.dig16, dec); if (rcp) return rcp; }
+  hipLaunchKernelGGL((k_count1<typename Prov::Dec>), dim3(pl.nblk1, gw), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_total);
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
-  hipLaunchKernelGGL((k_scatter1<Src>), dim3(pl.nblk1), dim3(256), 0, st, src, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
+  hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(pl.nblk1, gw), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
   hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.bin_start, w.tile_prefix, w.meta, w.bucket_count);
   hipLaunchKernelGGL(k_bucketscan, dim3((pl.nbins + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
   hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.bin_start, w.tile_prefix, w.meta,
@@ -563,8 +588,8 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   MsmPlan mp = make_msm_plan(ctx, curve, n);
   if (wb > we || we > mp.W) return fail(ctx, LEMSM_ERR_BAD_ARG, "window range out of bounds");
   auto make_src = [&](size_t s0, u32) {
-    PipSrc s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
-    memcpy(s.kadd, mp.kadd, 32); return s;
+    PipProvider s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
+    memcpy(s.kadd.k, mp.kadd, 32); return s;
   };
   return run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, out);
 }
@@ -621,8 +646,8 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   int rc = lhs_digits(ctx, curve, d_scalars, n, lp, ctx->in_aux, dg);
   if (rc) return rc;
   // the digit matrix is position-major over the whole n; slabs index it with an offset
-  auto make_src = [&](size_t s0, u32) { NegSrc s; s.digitsT = dg.digitsT + s0; return s; };
-  // NegSrc indexes digitsT[w * pl.n + j] with pl.n = slab size, so multi-slab inputs need the
+  auto make_src = [&](size_t s0, u32) { NegProvider s; s.digitsT = dg.digitsT + s0; return s; };
+  // NegDec indexes digitsT[w * pl.n + j] with pl.n = slab size, so multi-slab inputs need the
   // full row stride: restrict the lhs path to one slab (n <= 2^24) for now.
   if (n > ((size_t)1 << MAX_SLAB_LOG)) return fail(ctx, LEMSM_ERR_BAD_ARG, "lhs path supports n <= 2^24 per call");
   rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, out);

@@ -18,12 +18,14 @@ struct GroupPlan {
   uint32_t n;        // points in this slab
   uint32_t c;        // window bits (Pippenger path; 0 on the negabase path)
   uint32_t nb;       // buckets per window: 2^(c-1) or B-1
+  uint32_t nbw;      // key stride of a window: nb rounded up to a multiple of 2^LB  (= BW << LB)
+  uint32_t BW;       // coarse bins per window (<= 256)
   uint32_t w0, w1;   // windows of this group
   uint32_t W;        // total windows of the MSM (top window is unsigned)
-  uint32_t NB;       // (w1-w0)*nb  buckets in this group
+  uint32_t NB;       // (w1-w0)*nbw keys in this group
   uint32_t LB;       // local bucket bits
-  uint32_t nbins;    // ceil(NB / 2^LB) <= MAX_BINS
-  uint32_t spb;      // scalars per pass-1 block
+  uint32_t nbins;    // (w1-w0)*BW <= MAX_BINS
+  uint32_t spb;      // scalars per pass-1 block (<= STAGE)
   uint32_t nblk1;    // pass-1 blocks = ceil(n / spb)
   uint32_t T2;       // entries per pass-2 tile
   uint32_t max_tiles;// upper bound on pass-2 tiles

@@ -78,7 +78,7 @@ struct XYZZ {
     F::sub(P, U2, acc.x);
     F::sub(R, S2, acc.y);
     if (F::is_zero(P)) {                 // same x: doubling or cancellation (rare; kept out of line)
-      if (F::is_zero(R)) dbl_affine(acc, x2, y2);
+      if (F::is_zero(R)) { pt res; fe xx = x2, yy = y2; dbl_affine(res, xx, yy); acc = res; }   // acc's address must not escape
       else set_identity(acc);
       return;
     }
@@ -106,7 +106,7 @@ struct XYZZ {
     F::sub(P, U2, U1);
     F::sub(R, S2, S1);
     if (F::is_zero(P)) {
-      if (F::is_zero(R)) { pt t = acc; dbl(acc, t); }
+      if (F::is_zero(R)) { pt t = acc, res; dbl(res, t); acc = res; }
       else set_identity(acc);
       return;
     }
