@@ -93,15 +93,23 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LEMSM_BENCH_DEVICE / LEMSM_BENCH_BACKEND exist only to rehearse the N > 1 code path on a
+    # one-GPU box (all ranks on cuda:0, gloo collectives); the driver's runs use LOCAL_RANK + nccl.
+    dev_index = int(os.environ.get("LEMSM_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("LEMSM_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = dev if backend == "nccl" else None
 
     from halo2_liam_eagen_msm_amd import Context
     from halo2_liam_eagen_msm_amd import dist as ldist
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     curve = args.curve
     cid = {"bn254_g1": 0, "grumpkin": 1}[curve]
     order = ORDER[curve]
@@ -124,10 +132,10 @@ def main():
         if args.workload == "msm":
             if world == 1:
                 return ctx.msm_device(cid, d_scalars.ptr, d_points.ptr, n)
-            return ldist.sharded_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, world, rank, dev)
+            return ldist.sharded_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, world, rank, coll_dev)
         if world == 1:
             return ctx.lhs_msm_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True)[0]
-        return ldist.sharded_lhs_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, args.base, world, rank, dev)[0]
+        return ldist.sharded_lhs_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, args.base, world, rank, coll_dev)[0]
 
     def sync():
         if world > 1:
@@ -146,7 +154,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -157,9 +165,10 @@ def main():
         launches = max(launches, 1)
         accum_ms = acc_ms / launches
         # pairs one launch processes: all n pairs, for this rank's share of the windows
-        achieved = BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+        # algorithmic bytes of one launch = 96 B x n x (this rank's share of the windows)
+        achieved = BYTES_PER_PAIR * n / world / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.workload, curve, logn, world),
                     "kernel": "k_accum1", "kernel_ms": round(accum_ms, 4), "pipeline_device_ms": round(tot_ms / args.steps, 4),
                     "note": "integer-ALU-bound path: 96 algorithmic B/pair vs 8 TB/s HBM; see DESIGN.md for the VALU roofline"}
         out = {
@@ -179,6 +188,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, curve, logn, world):
+    """HBM bytes per k_accum1 launch from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC cannot be collected from inside
+    the process, so the figure is looked up for the exact workload and is null otherwise."""
+    path = os.path.join(ROOT, "profiles", "traffic_accum1.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    key = "%s/%s/2^%d/x%d" % (workload, curve, logn, world)
+    ent = table.get(key)
+    return None if ent is None else ent["bytes_per_launch"]
 
 
 def cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args):
