@@ -158,6 +158,61 @@ __global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, const u32* __re
 }
 
 // ------------------------------------------------------------------------------------
+// later edge-record levels: one record per lane, wavefront segmented scan (6 shuffle + add
+// steps), so a level is 6 additions deep and shrinks the record list 32x.  A run that lies inside
+// its wave goes to bucket_sum; per wave at most two edge records survive (its first run if it
+// continues from the previous wave, its last run if it continues into the next), written with
+// the same filler rule as above.
+// ------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(256) void k_segwave(u32 R, const u32* __restrict__ in_key, const char* __restrict__ in_pt,
+                                                 char* __restrict__ bucket_sum, u32* __restrict__ out_key,
+                                                 char* __restrict__ out_pt) {
+  const u32 gid = blockIdx.x * 256 + threadIdx.x;
+  const u32 lane = threadIdx.x & 63u, wave = gid >> 6;
+  const u32 wbase = wave << 6;
+  if (wbase >= R) return;
+  u32 key = gid < R ? in_key[gid] : KEY_NONE;
+  typename G::pt acc;
+  if (key != KEY_NONE) G::load(acc, in_pt + (size_t)gid * G::PT_BYTES); else G::set_identity(acc);
+  // neighbours across the wave boundary
+  u32 prev_glob = wbase > 0 ? in_key[wbase - 1] : KEY_NONE;
+  u32 next_glob = wbase + 64 < R ? in_key[wbase + 64] : KEY_NONE;
+  u32 kprev = __shfl_up(key, 1); if (lane == 0) kprev = prev_glob;
+  u32 knext = __shfl_down(key, 1); if (lane == 63) knext = next_glob;
+  const u32 key0 = __shfl(key, 0);
+#pragma unroll 1
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 k2 = __shfl_up(key, d);
+    typename G::pt q; G::shfl_up(q, acc, d);
+    bool take = lane >= (u32)d && key != KEY_NONE && k2 == key;
+    if (!take) G::set_identity(q);
+    G::add(acc, q);
+  }
+  const bool last_of_run = key != KEY_NONE && knext != key;         // run ends inside the wave
+  const bool open_end = key != KEY_NONE && lane == 63 && knext == key;   // run continues into the next wave
+  const bool from_lane0 = key == key0;                                // run started at lane 0
+  const bool before = from_lane0 && prev_glob == key && key != KEY_NONE;
+  const bool holder = last_of_run || open_end;                       // lane holding its run's in-wave sum
+  const bool edge = holder && (before || open_end);
+  if (holder && !edge) G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc);
+  unsigned long long em = __ballot(edge);
+  const u32 nedge = __popcll(em);
+  const u32 o0 = 2 * wave;
+  if (edge) {
+    u32 rank = __popcll(em & ((1ull << lane) - 1ull));
+    out_key[o0 + rank] = key;
+    G::store(out_pt + (size_t)(o0 + rank) * G::PT_BYTES, acc);
+    if (nedge == 1) {            // lone record: identity filler of the same key keeps the run contiguous
+      typename G::pt id; G::set_identity(id);
+      out_key[o0 + 1] = key;
+      G::store(out_pt + (size_t)(o0 + 1) * G::PT_BYTES, id);
+    }
+  }
+  if (nedge == 0 && lane == 0) { out_key[o0] = KEY_NONE; out_key[o0 + 1] = KEY_NONE; }
+}
+
+// ------------------------------------------------------------------------------------
 // bucket reduction: pairwise-add pyramid.  One launch per step; a step is a list of tasks
 //   dst[i] = src[(2i)*stride + phase] + src[(2i+1)*stride + phase],   i < count
 // applied to every window.  Arena offsets are in points (128 B); src indices >= src_valid

@@ -40,6 +40,7 @@ const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUN
 // heavy kernels are instantiated in inst_*.hip
 #define LEMSM_EXTERN_G(G)                                                                                   \
   extern template __global__ void lemsm::k_segreduce<G>(u32, u32, const u32*, const char*, char*, u32*, char*); \
+  extern template __global__ void lemsm::k_segwave<G>(u32, const u32*, const char*, char*, u32*, char*);                     \
   extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
 #define LEMSM_EXTERN_ACC(G, W) \
   extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
@@ -56,6 +57,14 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// bucket-reduction pyramid: per step a list of pairwise-add tasks (kernels_ec.cuh)
+struct PyrPlan {
+  std::vector<std::vector<PyrTask>> steps;   // steps[s-1] for s = 1..L
+  std::vector<u32> step_max_count;
+  CopyTask copy;                              // U_{L-1} = A^{L-1}[1]
+};
+struct PyrCacheEntry { DevBuf buf; PyrPlan pp; };   // task tables resident on the device
+
 }  // namespace
 
 struct lemsm_ctx {
@@ -69,7 +78,7 @@ struct lemsm_ctx {
   std::string last_error;
   long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0;
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
-  std::map<u64, DevBuf> pyr_cache;   // task tables keyed by (nb, gw)
+  std::map<std::vector<u32>, PyrCacheEntry> pyr_cache;   // keyed by (NBpad, nb, nbw, nbp, L, gw)
 };
 
 namespace {
@@ -175,11 +184,6 @@ MsmPlan make_msm_plan(const lemsm_ctx* ctx, int curve, size_t n) {
 template <class F> struct FieldTag {};
 
 // ---- pyramid task tables ----
-struct PyrPlan {
-  std::vector<std::vector<PyrTask>> steps;   // steps[s-1] for s = 1..L
-  std::vector<u32> step_max_count;
-  CopyTask copy;                              // U_{L-1} = A^{L-1}[1]
-};
 
 // arena offsets (in points) for one group
 struct ArenaLayout {
@@ -248,12 +252,11 @@ struct GroupWs {
   uint16_t* dig16;
   u32* entries; u32* sorted;
   u32* rec_key_a; char* rec_pt_a; u32* rec_key_b; char* rec_pt_b;
-  PyrTask* tasks; CopyTask* copy_task;
   size_t zero_begin, zero_bytes;   // contiguous region to memset(0) per group (offset from base)
   size_t total;
 };
 
-const u32 L2_RECORDS = 8;
+const u32 L2_RECORDS = 8;     // records per thread at the first edge-record level
 
 GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t ntasks_total, size_t ptb) {
   GroupWs w; size_t off = 0;
@@ -274,7 +277,6 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t R1 = 2 * (size_t)pl.nthr1;
   size_t R2 = 2 * ((R1 + L2_RECORDS - 1) / L2_RECORDS);
   size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * ptb + 256), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * ptb + 256);
-  size_t o_tasks = take(ntasks_total * sizeof(PyrTask) + 64), o_copy = take(sizeof(CopyTask) + 64);
   w.total = off;
   if (base) {
     w.bin_total = (u32*)(base + o_bin_total); w.bin_cursor = (u32*)(base + o_bin_cursor);
@@ -284,7 +286,6 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
     w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc); w.dig16 = (uint16_t*)(base + o_dig);
     w.entries = (u32*)(base + o_entries); w.sorted = (u32*)(base + o_sorted);
     w.rec_key_a = (u32*)(base + o_rka); w.rec_pt_a = base + o_rpa; w.rec_key_b = (u32*)(base + o_rkb); w.rec_pt_b = base + o_rpb;
-    w.tasks = (PyrTask*)(base + o_tasks); w.copy_task = (CopyTask*)(base + o_copy);
   }
   w.zero_begin = z0; w.zero_bytes = zend - z0;
   return w;
@@ -358,21 +359,29 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   u32 gw = pl.w1 - pl.w0;
   u32 NBpad = pl.nbins << pl.LB;
   ArenaLayout ar = make_arena(NBpad, nbp, gw, L);
-  PyrPlan pp = make_pyr_plan(ar, pl.nb, pl.nbw, nbp, L);
+  // pyramid task tables: built and uploaded once per plan shape, then reused
+  std::vector<u32> pkey = {NBpad, pl.nb, pl.nbw, nbp, L, gw};
+  auto pit = ctx->pyr_cache.find(pkey);
+  if (pit == ctx->pyr_cache.end()) {
+    PyrCacheEntry ent;
+    ent.pp = make_pyr_plan(ar, pl.nb, pl.nbw, nbp, L);
+    std::vector<PyrTask> flat;
+    for (auto& s : ent.pp.steps) flat.insert(flat.end(), s.begin(), s.end());
+    size_t tb = align_up(flat.size() * sizeof(PyrTask), 256);
+    int rcr = reserve(ctx, ent.buf, tb + sizeof(CopyTask) + 64); if (rcr) return rcr;
+    HIPCHK(ctx, hipMemcpy(ent.buf.p, flat.data(), flat.size() * sizeof(PyrTask), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy((char*)ent.buf.p + tb, &ent.pp.copy, sizeof(CopyTask), hipMemcpyHostToDevice));
+    pit = ctx->pyr_cache.emplace(pkey, std::move(ent)).first;
+  }
+  const PyrPlan& pp = pit->second.pp;
   size_t ntasks_total = 0;
   for (auto& s : pp.steps) ntasks_total += s.size();
+  PyrTask* d_tasks = (PyrTask*)pit->second.buf.p;
+  CopyTask* d_copy = (CopyTask*)((char*)pit->second.buf.p + align_up(ntasks_total * sizeof(PyrTask), 256));
   const size_t ptb = G::PT_BYTES;
   GroupWs w = carve(ws_base, pl, ar, ntasks_total, ptb);
 
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
-  // upload task tables (small; pageable memcpy is synchronous w.r.t. host, fine)
-  {
-    std::vector<PyrTask> flat;
-    for (auto& s : pp.steps) flat.insert(flat.end(), s.begin(), s.end());
-    HIPCHK(ctx, hipMemcpyAsync(w.tasks, flat.data(), flat.size() * sizeof(PyrTask), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(w.copy_task, &pp.copy, sizeof(CopyTask), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));   // flat/pp are stack objects
-  }
 
   typename Prov::Dec dec;
   { int rcp = prov.prepare(ctx, pl, w.dig16, dec); if (rcp) return rcp; }
@@ -404,12 +413,21 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   {
     u32 R = 2 * pl.nthr1;
     u32* ik = w.rec_key_a; char* ip = w.rec_pt_a; u32* ok = w.rec_key_b; char* op = w.rec_pt_b;
-    for (;;) {
+    // first level: 8 records per thread, serial (work-efficient while most records are real);
+    // later levels: one record per lane with a wavefront segmented scan (6 additions deep, 32x shrink)
+    {
       u32 nthr = (R + L2_RECORDS - 1) / L2_RECORDS;
       hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, L2_RECORDS, ik, ip,
                          w.arena + (size_t)ar.bucket_off * ptb, ok, op);
-      if (nthr == 1) break;
       R = 2 * nthr;
+      std::swap(ik, ok); std::swap(ip, op);
+    }
+    for (;;) {
+      u32 nwaves = (R + 63) / 64;
+      hipLaunchKernelGGL((k_segwave<G>), dim3((nwaves + 3) / 4), dim3(256), 0, st, R, ik, ip,
+                         w.arena + (size_t)ar.bucket_off * ptb, ok, op);
+      if (nwaves == 1) break;
+      R = 2 * nwaves;
       std::swap(ik, ok); std::swap(ip, op);
     }
   }
@@ -420,11 +438,11 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       auto& tasks = pp.steps[s - 1];
       u32 maxc = pp.step_max_count[s - 1];
       size_t threads = (size_t)tasks.size() * maxc * gw;
-      hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, w.tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
+      hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, d_tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
       toff += tasks.size();
     }
     u32 cthreads = gw * (u32)(ptb / 16);
-    hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, w.copy_task, 1u, gw, (u32)ptb, w.arena);
+    hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, d_copy, 1u, gw, (u32)ptb, w.arena);
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(d_out, w.arena + (size_t)ar.out_off * ptb, (size_t)gw * (L + 1) * ptb, hipMemcpyDeviceToDevice, st));
@@ -803,7 +821,7 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux}) if (b->p) (void)hipFree(b->p);
-  for (auto& kv : ctx->pyr_cache) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -123,6 +123,15 @@ struct XYZZ {
 
   static __device__ __forceinline__ void neg(pt& p) { F::neg(p.y, p.y); }
 
+  // lane i receives lane (i - d)'s point (wave64)
+  static __device__ __forceinline__ void shfl_up(pt& r, const pt& p, int d) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      r.x.v[i] = __shfl_up(p.x.v[i], d); r.y.v[i] = __shfl_up(p.y.v[i], d);
+      r.zz.v[i] = __shfl_up(p.zz.v[i], d); r.zzz.v[i] = __shfl_up(p.zzz.v[i], d);
+    }
+  }
+
   // memory format of an XYZZ point: 4 x 32 bytes (x, y, zz, zzz), raw Montgomery limbs
   static constexpr u32 PT_BYTES = 128;
   static __device__ __forceinline__ void load(pt& p, const void* mem) {

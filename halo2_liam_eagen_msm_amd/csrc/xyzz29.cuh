@@ -136,6 +136,15 @@ struct XYZZ29 {
     F::mul(t, acc.zzz, q.zzz); F::mul(acc.zzz, t, PPP);
   }
 
+  // lane i receives lane (i - d)'s point (wave64)
+  static __device__ __forceinline__ void shfl_up(pt& r, const pt& p, int d) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      r.x.l[i] = __shfl_up(p.x.l[i], d); r.y.l[i] = __shfl_up(p.y.l[i], d);
+      r.zz.l[i] = __shfl_up(p.zz.l[i], d); r.zzz.l[i] = __shfl_up(p.zzz.l[i], d);
+    }
+  }
+
   // Memory format of a point of this arithmetic: the 36 raw limbs (x, y, zz, zzz; 9 x i32 each)
   // + 4 pad words = 160 bytes, NOT canonicalised: storing is ten 16-byte stores.  (Canonical
   // packing costs ~900 instructions per point and the flush branch of k_accum1 is taken by some
