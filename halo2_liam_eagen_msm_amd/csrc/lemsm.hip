@@ -69,14 +69,17 @@ struct PyrCacheEntry { DevBuf buf; PyrPlan pp; };   // task tables resident on t
 
 struct lemsm_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // accumulate stream (and everything single-stream)
+  hipStream_t stream_sort = nullptr;   // digit + sort passes of the next window group (high priority)
+  hipStream_t stream_tail = nullptr;   // edge-record levels + pyramid of the previous group
+  std::vector<hipEvent_t> evpool;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf ws;        // workspace arena
   DevBuf in_s;      // staged scalars (host-pointer entries)
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0;
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   std::map<std::vector<u32>, PyrCacheEntry> pyr_cache;   // keyed by (NBpad, nb, nbw, nbp, L, gw)
 };
@@ -338,8 +341,8 @@ u32 max_group_windows(u32 nb) {
 struct PipProvider {
   const uint4* scalars; KAdd kadd;
   typedef PipDec Dec;
-  int prepare(lemsm_ctx* ctx, const GroupPlan& pl, uint16_t* dig16, Dec& dec) const {
-    hipLaunchKernelGGL(k_pip_digits, dim3((pl.n + 255) / 256), dim3(256), 0, ctx->stream, scalars, kadd, pl, dig16);
+  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, Dec& dec) const {
+    hipLaunchKernelGGL(k_pip_digits, dim3((pl.n + 255) / 256), dim3(256), 0, st, scalars, kadd, pl, dig16);
     dec.dig16 = dig16;
     return LEMSM_OK;
   }
@@ -347,15 +350,19 @@ struct PipProvider {
 struct NegProvider {
   const uint8_t* digitsT;
   typedef NegDec Dec;
-  int prepare(lemsm_ctx*, const GroupPlan&, uint16_t*, Dec& dec) const { dec.digitsT = digitsT; return LEMSM_OK; }
+  int prepare(lemsm_ctx*, hipStream_t, const GroupPlan&, uint16_t*, Dec& dec) const { dec.digitsT = digitsT; return LEMSM_OK; }
 };
 
 // Runs one window group [w0,w1): sort + accumulate + reduce; results (gw x (L+1) XYZZ points)
 // are left in the arena's out area and copied to d_out (device) + gslot.
 template <class G, class Prov>
 int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
-              char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, bool time_it) {
-  hipStream_t st = ctx->stream;
+              char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, hipStream_t s_sort, hipStream_t s_acc,
+              hipStream_t s_tail, hipEvent_t ev_sorted, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
+  // Three queues: the sort passes of this group may run while the previous group accumulates
+  // (s_sort), the accumulate kernels of all groups run back to back (s_acc), and this group's
+  // edge-record levels + pyramid overlap the next group's accumulation (s_tail).
+  hipStream_t st = s_sort;
   u32 gw = pl.w1 - pl.w0;
   u32 NBpad = pl.nbins << pl.LB;
   ArenaLayout ar = make_arena(NBpad, nbp, gw, L);
@@ -384,7 +391,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
 
   typename Prov::Dec dec;
-  { int rcp = prov.prepare(ctx, pl, w.dig16, dec); if (rcp) return rcp; }
+  { int rcp = prov.prepare(ctx, st, pl, w.dig16, dec); if (rcp) return rcp; }
   hipLaunchKernelGGL((k_count1<typename Prov::Dec>), dim3(pl.nblk1, gw), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_total);
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
   hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(pl.nblk1, gw), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
@@ -393,7 +400,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.bin_start, w.tile_prefix, w.meta,
                      w.bucket_start, w.bucket_cursor, w.sorted);
 
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+  HIPCHK(ctx, hipEventRecord(ev_sorted, s_sort));
+  st = s_acc;
+  HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_sorted, 0));
+  HIPCHK(ctx, hipEventRecord(ev_acc0, s_acc));
   {
     dim3 grid((pl.nthr1 + 255) / 256), blk(256);
     char* bsum = w.arena + (size_t)ar.bucket_off * ptb;
@@ -407,7 +417,9 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
     }
   }
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+  HIPCHK(ctx, hipEventRecord(ev_acc1, s_acc));
+  st = s_tail;
+  HIPCHK(ctx, hipStreamWaitEvent(s_tail, ev_acc1, 0));
 
   // edge-record levels
   {
@@ -525,54 +537,74 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   u32 nw = we - wb;
   host_out.assign((size_t)nw * (L + 1), HGp::identity());
   if (n == 0 || nw == 0) return LEMSM_OK;
-  hipStream_t st = ctx->stream;
   const size_t SLAB = (size_t)1 << MAX_SLAB_LOG;
   u32 gmax = max_group_windows(nb);
-  // workspace sizing over all (slab, group) combinations
-  size_t need = 0;
-  for (size_t s0 = 0; s0 < n; s0 += SLAB) {
-    u32 sn = (u32)std::min(SLAB, n - s0);
-    for (u32 g0 = wb; g0 < we; g0 += gmax) {
-      GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, g0, std::min(we, g0 + gmax), d);
-      need = std::max(need, group_ws_bytes(pl, nbp, L, G::PT_BYTES));
+  const size_t ptb = G::PT_BYTES;
+  // Window groups of this call.  Default: as few as the bin limit allows (one at c = 16).  With
+  // option "groups" > 1 the sort / accumulate / tail of neighbouring groups run on three queues;
+  // measured (profiles/r01/pipelined_groups_trace.txt) this does NOT pay on MI355X: k_accum1 is
+  // power-bound, so sort kernels running beside it slow it down by as much as they hide.
+  u32 ngroups = 1;
+  if (ctx->opt_groups > 0) ngroups = std::min((u32)ctx->opt_groups, nw);
+  u32 gsz = std::min(gmax, (nw + ngroups - 1) / ngroups);
+  struct Grp { u32 g0, g1; size_t off; };
+  std::vector<Grp> groups;
+  size_t ws_total = 0;
+  {
+    u32 sn0 = (u32)std::min(SLAB, n);
+    for (u32 g0 = wb; g0 < we; g0 += gsz) {
+      u32 g1 = std::min(we, g0 + gsz);
+      GroupPlan pl = make_group_plan(ctx, sn0, c, nb, W, g0, g1, d);
+      groups.push_back({g0, g1, ws_total});
+      ws_total += align_up(group_ws_bytes(pl, nbp, L, ptb), 256);
     }
   }
-  need = align_up(need, 256);
-  const size_t ptb = G::PT_BYTES;
   size_t out_bytes = align_up((size_t)nw * (L + 1) * ptb, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
-  int rc = reserve(ctx, ctx->ws, need + out_bytes + conv_bytes + 4096);
+  int rc = reserve(ctx, ctx->ws, ws_total + out_bytes + conv_bytes + 4096);
   if (rc) return rc;
   char* ws_base = (char*)ctx->ws.p;
-  char* d_out = ws_base + need;
+  char* d_out = ws_base + ws_total;
   char* d_conv = d_out + out_bytes;
+  while (ctx->evpool.size() < 3 * groups.size()) {
+    hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e);
+  }
+  hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream, s_tail = ctx->stream_tail;
+  if (groups.size() == 1) { s_sort = s_acc; s_tail = s_acc; }   // one queue: exact event timing, no cross-queue waits
+  HIPCHK(ctx, hipStreamSynchronize(s_acc));   // inputs staged / digits produced on the main stream are complete
   std::vector<host::pt> tmp;
   std::vector<char> raw((size_t)nw * (L + 1) * ptb);
-  HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+  HIPCHK(ctx, hipEventRecord(ctx->ev[0], s_sort));
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
   for (size_t s0 = 0; s0 < n; s0 += SLAB) {
     u32 sn = (u32)std::min(SLAB, n - s0);
     const char* pts = (const char*)d_points + s0 * 64;
     if constexpr (G::CONVERTED_DOMAIN) {
-      hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, st, (const uint4*)pts, (uint4*)d_conv, sn);
+      hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, s_acc, (const uint4*)pts, (uint4*)d_conv, sn);
       pts = d_conv;
     }
-    for (u32 g0 = wb; g0 < we; g0 += gmax) {
-      u32 g1 = std::min(we, g0 + gmax);
-      GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, g0, g1, d);
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+      const Grp& gr = groups[gi];
+      GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, gr.g0, gr.g1, d);
       auto src = make_src(s0, sn);
-      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base, d_out + (size_t)(g0 - wb) * (L + 1) * ptb, true);
+      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base + gr.off, d_out + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
+                        s_sort, s_acc, s_tail, ctx->evpool[3 * gi], ctx->evpool[3 * gi + 1], ctx->evpool[3 * gi + 2]);
       if (rc) return rc;
-      HIPCHK(ctx, hipStreamSynchronize(st));
-      float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    }
+    // drain: everything of this slab (the workspace is reused by the next slab)
+    HIPCHK(ctx, hipStreamSynchronize(s_sort));
+    HIPCHK(ctx, hipStreamSynchronize(s_acc));
+    HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, s_tail));
+    HIPCHK(ctx, hipStreamSynchronize(s_tail));
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+      float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->evpool[3 * gi + 1], ctx->evpool[3 * gi + 2]));
       ctx->t_accum_ms += ms; ctx->n_accum++;
     }
-    HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
     from_device_records<P64, G>(raw, tmp);
     if (s0 == 0) host_out = tmp;
     else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = HGp::add(host_out[i], tmp[i]);
   }
+  hipStream_t st = s_tail;
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
   float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -810,7 +842,13 @@ int lemsm_create(int device, lemsm_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return LEMSM_ERR_HIP;
   lemsm_ctx* c = new lemsm_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream_sort, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream_tail, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
+  }
   for (int i = 0; i < 4; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
   *out = c;
   return LEMSM_OK;
@@ -820,6 +858,9 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream_sort) { (void)hipStreamSynchronize(ctx->stream_sort); (void)hipStreamDestroy(ctx->stream_sort); }
+  if (ctx->stream_tail) { (void)hipStreamSynchronize(ctx->stream_tail); (void)hipStreamDestroy(ctx->stream_tail); }
+  for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
   for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -834,6 +875,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return LEMSM_ERR_BAD_ARG; ctx->opt_window_bits = value; }
   else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
+  else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }
   else if (!strcmp(name, "field")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_field = value; }
   else return LEMSM_ERR_BAD_ARG;
