@@ -38,16 +38,47 @@ struct KAdd { u32 k[8]; };
 // of s' are written window-major (dig16[(w-w0)*n + j], one coalesced 2-byte column per window) so
 // that the sort passes stream one window at a time.
 __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ scalars, KAdd kadd, GroupPlan pl,
-                                                    uint16_t* __restrict__ dig16) {
-  u32 j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= pl.n) return;
-  uint4 a = scalars[2 * (size_t)j], b = scalars[2 * (size_t)j + 1];
-  u32 s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  u32 cy = 0;
+                                                    uint16_t* __restrict__ dig16, u32* __restrict__ block_counts,
+                                                    u32* __restrict__ bin_total) {
+  // one block = one pass-1 range of spb scalars, all windows of the group: writes the digit
+  // columns AND the per-(window, range, bin) counts the scatter needs (no separate count pass)
+  __shared__ u32 hist[MAX_BINS];
+  const u32 tid = threadIdx.x, r = blockIdx.x;
+  for (u32 i = tid; i < pl.nbins; i += 256) hist[i] = 0;
+  __syncthreads();
+  const u32 half = 1u << (pl.c - 1);
+  u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
+  for (u32 jb = j0 + tid; jb < j1; jb += 256 * 4) {
+    uint4 a[4], b[4];
 #pragma unroll
-  for (int i = 0; i < 8; i++) s[i] = __builtin_addc(s[i], kadd.k[i], cy, &cy);
-  for (u32 w = pl.w0; w < pl.w1; w++)
-    dig16[(size_t)(w - pl.w0) * pl.n + j] = (uint16_t)extract_bits(s, w * pl.c, pl.c);
+    for (int u = 0; u < 4; u++) {     // four scalars in flight per thread
+      u32 j = jb + 256u * u;
+      if (j < j1) { a[u] = scalars[2 * (size_t)j]; b[u] = scalars[2 * (size_t)j + 1]; }
+      else { a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      u32 j = jb + 256u * u;
+      if (j >= j1) continue;
+      u32 s[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
+      u32 cy = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) s[i] = __builtin_addc(s[i], kadd.k[i], cy, &cy);
+      for (u32 w = pl.w0; w < pl.w1; w++) {
+        u32 raw = extract_bits(s, w * pl.c, pl.c);
+        dig16[(size_t)(w - pl.w0) * pl.n + j] = (uint16_t)raw;
+        u32 bucket = (w + 1 < pl.W) ? (raw < half ? half - raw : raw - half) : raw;
+        if (bucket) atomicAdd(&hist[(w - pl.w0) * pl.BW + ((bucket - 1u) >> pl.LB)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (u32 i = tid; i < pl.nbins; i += 256) {
+    u32 cnt = hist[i];
+    u32 wl = i / pl.BW, bin = i - wl * pl.BW;
+    block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + bin] = cnt;
+    if (cnt) atomicAdd(&bin_total[i], cnt);
+  }
 }
 
 // decoders: bucket (0 = skip) and sign of scalar j in window w
@@ -101,20 +132,28 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* total, u32* wsum 
 // consecutive lanes on consecutive addresses: scattered 4-byte stores cost ~16x write
 // amplification in HBM (the first version of this pass ran at 0.5 TB/s).
 // ------------------------------------------------------------------------------------
-static const u32 STAGE = 8192;
+static const u32 STAGE = 4096;     // pass-1 range per block (more resident blocks hide its latency chain)
+static const u32 STAGE2 = 8192;    // pass-2 tile (longer runs per local bucket)
 
 template <class Dec>
 __global__ __launch_bounds__(256) void k_count1(Dec dec, GroupPlan pl, u32* __restrict__ block_counts,
                                                 u32* __restrict__ bin_total) {
   __shared__ u32 hist[256];
-  const u32 tid = threadIdx.x, r = blockIdx.x, wl = blockIdx.y, w = pl.w0 + wl;
+  const u32 tid = threadIdx.x, wl = blockIdx.x, r = blockIdx.y, w = pl.w0 + wl;
   hist[tid] = 0;
   __syncthreads();
   u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
-  for (u32 j = j0 + tid; j < j1; j += 256) {
-    u32 bucket, sign; dec.get(j, w, pl, bucket, sign);
-    if (bucket) atomicAdd(&hist[(bucket - 1u) >> pl.LB], 1u);
+  constexpr int PER = STAGE / 256;
+  u32 bk[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    u32 j = j0 + tid + 256u * k, sign;
+    bk[k] = 0;
+    if (j < j1) dec.get(j, w, pl, bk[k], sign);
   }
+#pragma unroll
+  for (int k = 0; k < PER; k++)
+    if (bk[k]) atomicAdd(&hist[(bk[k] - 1u) >> pl.LB], 1u);
   __syncthreads();
   if (tid < pl.BW) {
     u32 cnt = hist[tid];
@@ -184,7 +223,22 @@ __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u
   __shared__ u32 wsum[4];
   __shared__ u32 stage[STAGE];
   __shared__ uint8_t sbin[STAGE];
-  const u32 tid = threadIdx.x, r = blockIdx.x, wl = blockIdx.y, w = pl.w0 + wl;
+  // grid = (windows, ranges): neighbouring blocks work on different windows, so the claim atomics
+  // of concurrently running blocks spread over gw x BW addresses instead of hammering BW of them
+  const u32 tid = threadIdx.x, wl = blockIdx.x, r = blockIdx.y, w = pl.w0 + wl;
+  const u32 lmask = (1u << pl.LB) - 1u;
+  u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
+  // Issue every load of the block up front -- the digit column (STAGE/256 per thread) and this
+  // block's bin counts -- so that their latencies overlap each other and the claim atomics
+  // (a rolled loop waits out one memory latency per entry: measured 3x slower).
+  constexpr int PER = STAGE / 256;
+  u32 bk[PER], sg[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    u32 j = j0 + tid + 256u * k;
+    bk[k] = 0; sg[k] = 0;
+    if (j < j1) dec.get(j, w, pl, bk[k], sg[k]);
+  }
   u32 cnt = tid < pl.BW ? block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + tid] : 0u;
   u32 total;
   u32 off = block_excl_scan_256(cnt, &total, wsum);
@@ -193,14 +247,13 @@ __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u
   gbase[tid] = cnt ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt) : 0u;
   lcur[tid] = 0;
   __syncthreads();
-  const u32 lmask = (1u << pl.LB) - 1u;
-  u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
-  for (u32 j = j0 + tid; j < j1; j += 256) {
-    u32 bucket, sign; dec.get(j, w, pl, bucket, sign);
-    if (bucket) {
-      u32 k = bucket - 1u, b = k >> pl.LB;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    if (bk[k]) {
+      u32 j = j0 + tid + 256u * k;
+      u32 kk = bk[k] - 1u, b = kk >> pl.LB;
       u32 q = lstart[b] + atomicAdd(&lcur[b], 1u);
-      stage[q] = j | ((k & lmask) << 24) | (sign << 31);
+      stage[q] = j | ((kk & lmask) << 24) | (sg[k] << 31);
       sbin[q] = (uint8_t)b;
     }
   }
@@ -214,32 +267,43 @@ __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u
 // ------------------------------------------------------------------------------------
 // pass 2: exact bucket sort inside each bin, one tile (<= T2 <= STAGE entries of one bin) per block
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ bool locate_tile(const GroupPlan& pl, const u32* __restrict__ bin_start,
-                                            const u32* __restrict__ tile_prefix, const u32* __restrict__ meta,
-                                            u32& bin, u32& off, u32& end) {
-  u32 t = blockIdx.x;
-  if (t >= meta[META_TILES]) return false;
+// tile table: one thread per tile finds its bin once (binary search over tile_prefix), so that
+// the two pass-2 kernels start with one 16-byte load instead of a dependent-load chain per block
+__global__ __launch_bounds__(256) void k_tilemap(GroupPlan pl, const u32* __restrict__ bin_start,
+                                                 const u32* __restrict__ tile_prefix, const u32* __restrict__ meta,
+                                                 uint4* __restrict__ tile_info) {
+  u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= pl.max_tiles) return;
+  if (t >= meta[META_TILES]) { tile_info[t] = make_uint4(0, 0, 0, 0); return; }
   u32 lo = 0, hi = pl.nbins;   // largest b with tile_prefix[b] <= t
   while (hi - lo > 1) {
     u32 mid = (lo + hi) >> 1;
     if (tile_prefix[mid] <= t) lo = mid; else hi = mid;
   }
-  bin = lo;
-  off = bin_start[bin] + (t - tile_prefix[bin]) * pl.T2;
-  end = min(off + pl.T2, bin_start[bin + 1]);
-  return true;
+  u32 off = bin_start[lo] + (t - tile_prefix[lo]) * pl.T2;
+  u32 end = min(off + pl.T2, bin_start[lo + 1]);
+  tile_info[t] = make_uint4(lo, off, end, 1u);
+}
+__device__ __forceinline__ bool locate_tile(const uint4* __restrict__ tile_info, u32& bin, u32& off, u32& end) {
+  uint4 ti = tile_info[blockIdx.x];
+  bin = ti.x; off = ti.y; end = ti.z;
+  return ti.w != 0;
 }
 
 __global__ __launch_bounds__(256) void k_count2(GroupPlan pl, const u32* __restrict__ entries,
-                                                const u32* __restrict__ bin_start, const u32* __restrict__ tile_prefix,
-                                                const u32* __restrict__ meta, u32* __restrict__ bucket_count) {
+                                                const uint4* __restrict__ tile_info, u32* __restrict__ bucket_count) {
   __shared__ u32 hist[1u << MAX_LB];
   u32 bin, off, end;
-  if (!locate_tile(pl, bin_start, tile_prefix, meta, bin, off, end)) return;
+  if (!locate_tile(tile_info, bin, off, end)) return;
   const u32 tid = threadIdx.x;
   if (tid < (1u << MAX_LB)) hist[tid] = 0;
   __syncthreads();
-  for (u32 i = off + tid; i < end; i += 256) atomicAdd(&hist[(entries[i] >> 24) & 127u], 1u);
+  constexpr int PER = STAGE2 / 256;    // T2 <= STAGE2
+  u32 e[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; e[k] = i < end ? entries[i] : 0xffffffffu; }
+#pragma unroll
+  for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; if (i < end) atomicAdd(&hist[(e[k] >> 24) & 127u], 1u); }
   __syncthreads();
   if (tid < (1u << pl.LB)) {
     u32 cnt = hist[tid];
@@ -264,21 +328,28 @@ __global__ __launch_bounds__(256) void k_bucketscan(GroupPlan pl, const u32* __r
 }
 
 __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __restrict__ entries,
-                                                  const u32* __restrict__ bin_start, const u32* __restrict__ tile_prefix,
-                                                  const u32* __restrict__ meta, const u32* __restrict__ bucket_start,
+                                                  const uint4* __restrict__ tile_info, const u32* __restrict__ bucket_start,
                                                   u32* __restrict__ bucket_cursor, u32* __restrict__ sorted) {
   __shared__ u32 hist[256];
   __shared__ u32 lstart[257];
   __shared__ u32 gbase[256];
   __shared__ u32 wsum[4];
-  __shared__ u32 stage[STAGE];
-  __shared__ uint8_t sloc[STAGE];
+  __shared__ u32 stage[STAGE2];
+  __shared__ uint8_t sloc[STAGE2];
   u32 bin, off, end;
-  if (!locate_tile(pl, bin_start, tile_prefix, meta, bin, off, end)) return;
+  if (!locate_tile(tile_info, bin, off, end)) return;
   const u32 tid = threadIdx.x;
   hist[tid] = 0;
   __syncthreads();
-  for (u32 i = off + tid; i < end; i += 256) atomicAdd(&hist[(entries[i] >> 24) & 127u], 1u);
+  constexpr int PER = STAGE2 / 256;    // T2 <= STAGE2
+  u32 e[PER], rk[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; e[k] = i < end ? entries[i] : 0xffffffffu; }
+#pragma unroll
+  for (int k = 0; k < PER; k++) {      // the histogram atomic also hands out the rank inside (tile, bucket)
+    u32 i = off + tid + 256u * k;
+    rk[k] = i < end ? atomicAdd(&hist[(e[k] >> 24) & 127u], 1u) : 0u;
+  }
   __syncthreads();
   u32 cnt = tid < (1u << pl.LB) ? hist[tid] : 0u;
   u32 total;
@@ -287,14 +358,16 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
   if (tid == 255) lstart[256] = total;
   u32 key = (bin << pl.LB) + tid;
   gbase[tid] = cnt ? bucket_start[key] + atomicAdd(&bucket_cursor[key], cnt) : 0u;
-  hist[tid] = 0;
   __syncthreads();
-  for (u32 i = off + tid; i < end; i += 256) {
-    u32 e = entries[i];
-    u32 l = (e >> 24) & 127u;
-    u32 q = lstart[l] + atomicAdd(&hist[l], 1u);
-    stage[q] = e & 0x80ffffffu;
-    sloc[q] = (uint8_t)l;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    u32 i = off + tid + 256u * k;
+    if (i < end) {
+      u32 l = (e[k] >> 24) & 127u;
+      u32 q = lstart[l] + rk[k];
+      stage[q] = e[k] & 0x80ffffffu;
+      sloc[q] = (uint8_t)l;
+    }
   }
   __syncthreads();
   for (u32 q = tid; q < total; q += 256) {

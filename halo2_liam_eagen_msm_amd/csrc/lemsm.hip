@@ -253,6 +253,7 @@ struct GroupWs {
   u32* bucket_count; u32* bucket_cursor; u32* bucket_start;
   u32* block_counts;
   uint16_t* dig16;
+  uint4* tile_info;
   u32* entries; u32* sorted;
   u32* rec_key_a; char* rec_pt_a; u32* rec_key_b; char* rec_pt_b;
   size_t zero_begin, zero_bytes;   // contiguous region to memset(0) per group (offset from base)
@@ -275,6 +276,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t o_bstart = take(((size_t)NBpad + 1) * 4);
   size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 4);
   size_t o_dig = take(pl.c ? (size_t)pl.n * (pl.w1 - pl.w0) * 2 + 16 : 16);
+  size_t o_tinfo = take((size_t)pl.max_tiles * 16 + 16);
   size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
   size_t o_entries = take(Mmax * 4 + 16), o_sorted = take(Mmax * 4 + 16);
   size_t R1 = 2 * (size_t)pl.nthr1;
@@ -286,7 +288,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
     w.bucket_count = (u32*)(base + o_bcount); w.bucket_cursor = (u32*)(base + o_bcursor);
     w.arena = base + o_arena;
     w.bin_start = (u32*)(base + o_bin_start); w.tile_prefix = (u32*)(base + o_tile_prefix); w.meta = (u32*)(base + o_meta);
-    w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc); w.dig16 = (uint16_t*)(base + o_dig);
+    w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc); w.dig16 = (uint16_t*)(base + o_dig); w.tile_info = (uint4*)(base + o_tinfo);
     w.entries = (u32*)(base + o_entries); w.sorted = (u32*)(base + o_sorted);
     w.rec_key_a = (u32*)(base + o_rka); w.rec_pt_a = base + o_rpa; w.rec_key_b = (u32*)(base + o_rkb); w.rec_pt_b = base + o_rpb;
   }
@@ -312,7 +314,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   g.nblk1 = (n + spb - 1) / spb;
   if (g.nblk1 == 0) g.nblk1 = 1;
   size_t Mmax = (size_t)n * (w1 - w0);
-  u32 T2 = ctx->opt_tile > 0 ? std::min((u32)ctx->opt_tile, (u32)STAGE) : (u32)STAGE;
+  u32 T2 = ctx->opt_tile > 0 ? std::min((u32)ctx->opt_tile, (u32)STAGE2) : (u32)STAGE2;
   g.T2 = T2;
   g.max_tiles = (u32)(Mmax / T2) + g.nbins + 1;
   u32 L1;
@@ -341,8 +343,9 @@ u32 max_group_windows(u32 nb) {
 struct PipProvider {
   const uint4* scalars; KAdd kadd;
   typedef PipDec Dec;
-  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, Dec& dec) const {
-    hipLaunchKernelGGL(k_pip_digits, dim3((pl.n + 255) / 256), dim3(256), 0, st, scalars, kadd, pl, dig16);
+  // digit columns + pass-1 counts in one kernel
+  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, u32* block_counts, u32* bin_total, Dec& dec) const {
+    hipLaunchKernelGGL(k_pip_digits, dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total);
     dec.dig16 = dig16;
     return LEMSM_OK;
   }
@@ -350,7 +353,11 @@ struct PipProvider {
 struct NegProvider {
   const uint8_t* digitsT;
   typedef NegDec Dec;
-  int prepare(lemsm_ctx*, hipStream_t, const GroupPlan&, uint16_t*, Dec& dec) const { dec.digitsT = digitsT; return LEMSM_OK; }
+  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t*, u32* block_counts, u32* bin_total, Dec& dec) const {
+    dec.digitsT = digitsT;
+    hipLaunchKernelGGL((k_count1<NegDec>), dim3(pl.w1 - pl.w0, pl.nblk1), dim3(256), 0, st, dec, pl, block_counts, bin_total);
+    return LEMSM_OK;
+  }
 };
 
 // Runs one window group [w0,w1): sort + accumulate + reduce; results (gw x (L+1) XYZZ points)
@@ -391,13 +398,13 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
 
   typename Prov::Dec dec;
-  { int rcp = prov.prepare(ctx, st, pl, w.dig16, dec); if (rcp) return rcp; }
-  hipLaunchKernelGGL((k_count1<typename Prov::Dec>), dim3(pl.nblk1, gw), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_total);
+  { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.block_counts, w.bin_total, dec); if (rcp) return rcp; }
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
-  hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(pl.nblk1, gw), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
-  hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.bin_start, w.tile_prefix, w.meta, w.bucket_count);
+  hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
+  hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
+  hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
   hipLaunchKernelGGL(k_bucketscan, dim3((pl.nbins + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
-  hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.bin_start, w.tile_prefix, w.meta,
+  hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info,
                      w.bucket_start, w.bucket_cursor, w.sorted);
 
   HIPCHK(ctx, hipEventRecord(ev_sorted, s_sort));
