@@ -36,7 +36,7 @@ SYMBOLS = [
     "lemsm_num_digits", "lemsm_negbase_decompose_batch",
     "lemsm_lhs_msm", "lemsm_lhs_msm_grumpkin", "lemsm_lhs_msm_bn254_g1", "lemsm_lhs_msm_device",
     "lemsm_lhs_plan", "lemsm_lhs_partial_device", "lemsm_lhs_combine",
-    "lemsm_precompute_multiplicities",
+    "lemsm_precompute_multiplicities", "lemsm_precompute_multiplicities_affine",
     "lemsm_jacobian_to_canonical",
     "lemsm_device_alloc", "lemsm_device_free", "lemsm_device_upload", "lemsm_device_download",
     "lemsm_device_gen_walk",
@@ -95,6 +95,7 @@ def load() -> ctypes.CDLL:
         "lemsm_lhs_partial_device": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint32, u8p, szp]),
         "lemsm_lhs_combine": (i, [i, ctypes.c_uint8, u8p, u64p, u64p]),
         "lemsm_precompute_multiplicities": (i, [vp, i, u64p, sz, ctypes.c_uint8, u64p]),
+        "lemsm_precompute_multiplicities_affine": (i, [vp, i, u64p, sz, ctypes.c_uint8, u64p]),
         "lemsm_jacobian_to_canonical": (i, [i, u64p, u8p]),
         "lemsm_device_alloc": (i, [vp, sz, ctypes.POINTER(vp)]),
         "lemsm_device_free": (i, [vp, vp]),

@@ -267,6 +267,13 @@ class Context:
         self._check(self.lib.lemsm_precompute_multiplicities(self.h, _curve_id(curve), _ptr(p), p.shape[0], base, _ptr(out)))
         return out
 
+    def precompute_multiplicities_affine(self, curve, pts_jacobian, base: int) -> np.ndarray:
+        """(n, base-1, 8): affine k*P_j, the table src/config.rs:542-560 fills."""
+        p = _limbs(pts_jacobian, 12)
+        out = np.zeros((p.shape[0], max(base - 1, 0), 8), np.uint64)
+        self._check(self.lib.lemsm_precompute_multiplicities_affine(self.h, _curve_id(curve), _ptr(p), p.shape[0], base, _ptr(out)))
+        return out
+
     def gen_walk(self, curve, q_affine: np.ndarray, n: int) -> DeviceBuffer:
         q = np.ascontiguousarray(q_affine, np.uint64).reshape(8)
         buf = self.alloc(max(n * 64, 16))

@@ -779,6 +779,42 @@ __global__ __launch_bounds__(256) void k_precompute_mult(const uint4* __restrict
   }
 }
 
+// [1P .. (base-1)P] per input point as AFFINE points (the form src/config.rs:542-560 writes into its
+// fixed column: the reference normalises every multiple with its own inversion, :550-554): one
+// thread per point, Montgomery's trick over its base-1 multiples (prefix products in scratch [k][n]).
+template <class F>
+__global__ __launch_bounds__(256) void k_precompute_mult_affine(const uint4* __restrict__ jac, u32 n, u32 base,
+                                                                uint4* __restrict__ out, char* __restrict__ scratch) {
+  typedef XYZZ<F> G; typedef typename F::fe fe;
+  u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  fe X, Y, Z; F::load(X, jac + (size_t)j * 6); F::load(Y, jac + (size_t)j * 6 + 2); F::load(Z, jac + (size_t)j * 6 + 4);
+  typename G::pt p;
+  if (F::is_zero(Z)) G::set_identity(p);
+  else { p.x = X; p.y = Y; F::sqr(p.zz, Z); F::mul(p.zzz, p.zz, Z); }
+  typename G::pt acc = p;
+  fe pref; F::set_one(pref);
+  for (u32 k = 1; k < base; k++) {
+    char* s = scratch + ((size_t)(k - 1) * n + j) * 160;
+    G::store(s, acc); F::store(s + 128, pref);
+    if (!G::is_identity(acc)) F::mul(pref, pref, acc.zzz);
+    G::add(acc, p);
+  }
+  fe inv; F::inv(inv, pref);
+  for (u32 k = base - 1; k >= 1; k--) {
+    const char* s = scratch + ((size_t)(k - 1) * n + j) * 160;
+    typename G::pt q; G::load(q, s); fe pr; F::load(pr, s + 128);
+    uint4* o = out + ((size_t)j * (base - 1) + (k - 1)) * 4;
+    if (G::is_identity(q)) { uint4 z = make_uint4(0, 0, 0, 0); o[0] = z; o[1] = z; o[2] = z; o[3] = z; continue; }
+    fe izzz, izz, x, y;
+    F::mul(izzz, inv, pr);
+    F::mul(inv, inv, q.zzz);
+    F::mul(izz, izzz, q.zz); F::sqr(izz, izz);
+    F::mul(x, q.x, izz); F::mul(y, q.y, izzz);
+    F::store(o, x); F::store(o + 2, y);
+  }
+}
+
 // P_i = (i+1) Q, thread t owns [t*KB, (t+1)*KB); affine output through a per-thread batch inversion.
 template <class F, int KB>
 __global__ __launch_bounds__(256) void k_gen_walk(const uint4* __restrict__ q_aff, u32 n, uint4* __restrict__ out, char* __restrict__ scratch) {
@@ -1077,6 +1113,30 @@ int lemsm_precompute_multiplicities(lemsm_ctx* ctx, int curve, const uint64_t* p
     hipLaunchKernelGGL((k_precompute_mult<FrDev>), dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)b, (u32)n, (u32)base, (uint4*)(b + in_bytes));
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(out, b + in_bytes, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LEMSM_OK;
+}
+
+int lemsm_precompute_multiplicities_affine(lemsm_ctx* ctx, int curve, const uint64_t* pts_jac, size_t n, uint8_t base, uint64_t* out) {
+  if (!ctx || (n && (!pts_jac || !out))) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (base < 2) return fail(ctx, LEMSM_ERR_BAD_BASE, "base must be >= 2");
+  if (n == 0 || base == 1) return LEMSM_OK;
+  if (n >= ((size_t)1 << 28)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t nm = n * (size_t)(base - 1);
+  size_t in_bytes = align_up(n * 96, 256), out_bytes = align_up(nm * 64, 256), scr_bytes = nm * 160;
+  rc = reserve(ctx, ctx->ws, in_bytes + out_bytes + scr_bytes + 256); if (rc) return rc;
+  char* b = (char*)ctx->ws.p;
+  HIPCHK(ctx, hipMemcpyAsync(b, pts_jac, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  if (curve == LEMSM_BN254_G1)
+    hipLaunchKernelGGL((k_precompute_mult_affine<FqDev>), dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)b, (u32)n, (u32)base,
+                       (uint4*)(b + in_bytes), b + in_bytes + out_bytes);
+  else
+    hipLaunchKernelGGL((k_precompute_mult_affine<FrDev>), dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)b, (u32)n, (u32)base,
+                       (uint4*)(b + in_bytes), b + in_bytes + out_bytes);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, b + in_bytes, nm * 64, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return LEMSM_OK;
 }

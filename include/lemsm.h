@@ -139,6 +139,12 @@ int lemsm_lhs_combine(int curve, uint8_t base, const uint8_t* partials_all_posit
 int lemsm_precompute_multiplicities(lemsm_ctx* ctx, int curve, const uint64_t* pts_jacobian, size_t n,
                                     uint8_t base, uint64_t* out_jacobian);
 
+/* Same multiples as affine (x,y) pairs, out_affine[(j*(base-1) + (k-1))*8 .. +8]: the form
+   src/config.rs:542-560 writes into the fixed table column (the reference inverts once per multiple,
+   :550-554; here one batched inversion per input point). */
+int lemsm_precompute_multiplicities_affine(lemsm_ctx* ctx, int curve, const uint64_t* pts_jacobian, size_t n,
+                                           uint8_t base, uint64_t* out_affine);
+
 /* ---- helpers ------------------------------------------------------------------------- */
 /* Jacobian -> canonical comparison form: affine x||y, 32-byte little-endian canonical
    (non-Montgomery) integers; identity = 64 zero bytes. */

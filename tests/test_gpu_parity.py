@@ -326,8 +326,65 @@ def test_precompute_multiplicities(ctx, curve):
                 assert canon(curve, got[j, k]) == canon(curve, exp[k]), (base, j, k)
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_precompute_multiplicities_affine_table(ctx, curve):
+    """the fixed-table form of src/config.rs:542-560: affine (x,y) of k*P_j"""
+    n = 37
+    pts_aff = cref.gen_points(curve.cid, 91, n)
+    pts = jacobian_with_random_z(curve, pts_aff, 92)
+    pts[5] = 0   # identity input -> identity multiples
+    for base in (2, 5, 16, 255):
+        got = ctx.precompute_multiplicities_affine(curve.cid, pts, base)
+        assert got.shape == (n, base - 1, 8)
+        for j in (0, 5, 17, n - 1):
+            pa = None if j == 5 else curve.raw_to_affine(pts_aff[j].tobytes())
+            for k in (1, 2, base - 1) if base > 2 else (1,):
+                exp = curve.mul(k, pa)
+                assert curve.raw_to_affine(got[j, k - 1].tobytes()) == exp, (base, j, k)
+
+
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 8191, 8193, 12289, 65535, 65537])
+def test_msm_ragged_sizes_around_block_and_tile_boundaries(ctx, n):
+    """sizes straddling the pass-1 range (4096), the pass-2 tile (8192) and 2^16; c = 16 forced so that
+    the big-bucket-count path (LB = 7, 256 bins per window) runs at small n"""
+    curve = pyref.BN254_G1
+    q = cref.gen_points(curve.cid, 300 + n % 7, 1)[0]
+    dp = ctx.gen_walk(curve.cid, q, n)
+    sc = cref.gen_scalars(curve.cid, 301 + n, n)
+    ds = ctx.to_device(sc)
+    exp = canon(curve, cref.scalar_mul(curve.cid, cref.walk_dot(curve.cid, sc), q))
+    assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)) == exp
+    ctx.set_option("window_bits", 16)
+    try:
+        out1 = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+        out2 = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+    finally:
+        ctx.set_option("window_bits", 0)
+    assert canon(curve, out1) == exp
+    assert canon(curve, out2) == exp          # repeatable (atomics reorder the summation, never the group element)
+
+
+def test_lhs_large_walk_relation(ctx):
+    """2^16-point negabase path (base 16, the bench configuration at reduced n) through the device entry"""
+    curve = pyref.GRUMPKIN
+    n, base = 1 << 16, 16
+    q = cref.gen_points(curve.cid, 411, 1)[0]
+    dp = ctx.gen_walk(curve.cid, q, n)
+    sc = cref.gen_scalars(curve.cid, 412, n, half=True)
+    ds = ctx.to_device(sc)
+    carry, carries = ctx.lhs_msm_device(curve.cid, ds.ptr, dp.ptr, n, base)
+    exp = canon(curve, cref.scalar_mul(curve.cid, cref.walk_dot(curve.cid, sc), q))
+    assert canon(curve, carry) == exp
+    assert canon(curve, carries[-1]) == exp
+    # carry_i recursion: carry_i = -B*carry_{i-1} + S_i  =>  all carries are multiples of Q; check the first non-trivial one
+    d = api.num_digits(curve.cid, base)
+    digs = ctx.negbase_decompose_batch(sc, base, d)
+    top = int(sum(int(digs[j, d - 1]) * (j + 1) for j in range(n)) % curve.order)
+    assert canon(curve, carries[0]) == canon(curve, cref.scalar_mul(curve.cid, top, q))
+
+
 # ------------------------------------------------------------------ larger sizes: properties
-@pytest.mark.parametrize("curve,logn", [(pyref.BN254_G1, 16), (pyref.GRUMPKIN, 16), (pyref.BN254_G1, 20)], ids=["bn254-2^16", "grumpkin-2^16", "bn254-2^20"])
+@pytest.mark.parametrize("curve,logn", [(pyref.BN254_G1, 16), (pyref.GRUMPKIN, 16), (pyref.BN254_G1, 20), (pyref.GRUMPKIN, 22)], ids=["bn254-2^16", "grumpkin-2^16", "bn254-2^20", "grumpkin-2^22"])
 def test_msm_walk_relation_large(ctx, curve, logn):
     """P_i = (i+1) Q  =>  sum s_i P_i == (sum s_i (i+1)) Q, checked with one scalar multiplication;
     the device-generated points are spot-checked against the oracle."""
