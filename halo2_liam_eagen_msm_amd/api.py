@@ -146,6 +146,8 @@ class Context:
         if rc == _lib.LEMSM_ERR_LEN_MISMATCH:
             raise LengthMismatch(rc, "incompatible amount of coefficients")
         if rc == _lib.LEMSM_ERR_SCALAR_OUT_OF_RANGE:
+            if bad_index is None:
+                bad_index = int(self.lib.lemsm_last_bad_index(self.h))
             raise ScalarOutOfRange(rc, msg, bad_index)
         if rc == _lib.LEMSM_ERR_BAD_BASE:
             raise BadBase(rc, msg)

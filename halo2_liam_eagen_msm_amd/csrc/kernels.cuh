@@ -32,14 +32,14 @@ __device__ __forceinline__ u32 extract_bits(const u32 (&s)[8], u32 bitpos, u32 c
   return (u32)(v >> sh) & ((1u << c) - 1u);
 }
 
-struct KAdd { u32 k[8]; };
+struct KAdd { u32 k[8]; u32 order[8]; };   // window offset constant K and the scalar-field order
 
 // Signed-window Pippenger: s' = s + K with K = sum_{w<W-1} 2^(c-1) 2^(cw).  The raw c-bit windows
 // of s' are written window-major (dig16[(w-w0)*n + j], one coalesced 2-byte column per window) so
 // that the sort passes stream one window at a time.
 __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ scalars, KAdd kadd, GroupPlan pl,
                                                     uint16_t* __restrict__ dig16, u32* __restrict__ block_counts,
-                                                    u32* __restrict__ bin_total) {
+                                                    u32* __restrict__ bin_total, u32* __restrict__ err) {
   // one block = one pass-1 range of spb scalars, all windows of the group: writes the digit
   // columns AND the per-(window, range, bin) counts the scatter needs (no separate count pass)
   __shared__ u32 hist[MAX_BINS];
@@ -61,6 +61,16 @@ __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ sc
       u32 j = jb + 256u * u;
       if (j >= j1) continue;
       u32 s[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
+      // scalars must be canonical (< order), as PrimeField::to_repr() guarantees; anything else is
+      // reported (LEMSM_ERR_SCALAR_OUT_OF_RANGE) and contributes nothing
+      u32 bw = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { u32 dmy = __builtin_subc(s[i], kadd.order[i], bw, &bw); (void)dmy; }
+      if (!bw) {
+        atomicAdd(&err[0], 1u); atomicMax(&err[1], ~j);
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = 0;
+      }
       u32 cy = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++) s[i] = __builtin_addc(s[i], kadd.k[i], cy, &cy);

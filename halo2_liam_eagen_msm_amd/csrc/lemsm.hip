@@ -81,6 +81,7 @@ struct lemsm_ctx {
   std::string last_error;
   long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0;
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
+  size_t bad_index = 0;
   std::map<std::vector<u32>, PyrCacheEntry> pyr_cache;   // keyed by (NBpad, nb, nbw, nbp, L, gw)
 };
 
@@ -248,6 +249,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Workspace carve for one window group.
 struct GroupWs {
+  u32* err;             // [0] = count of non-canonical scalars, [1] = ~(smallest offending index); first word of the group workspace
   char* arena;          // points arena (bucket sums, pyramid, out)
   u32* bin_total; u32* bin_cursor; u32* bin_start; u32* tile_prefix; u32* meta;
   u32* bucket_count; u32* bucket_cursor; u32* bucket_start;
@@ -268,6 +270,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   u32 NBpad = pl.nbins << pl.LB;
   // zeroed region first: bin_total, bin_cursor, bucket_count, bucket_cursor, bucket sums
   size_t z0 = off;
+  size_t o_err = take(64);
   size_t o_bin_total = take(MAX_BINS * 4), o_bin_cursor = take(MAX_BINS * 4);
   size_t o_bcount = take((size_t)NBpad * 4), o_bcursor = take((size_t)NBpad * 4);
   size_t o_arena = take((size_t)ar.total_points * ptb);
@@ -284,6 +287,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * ptb + 256), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * ptb + 256);
   w.total = off;
   if (base) {
+    w.err = (u32*)(base + o_err);
     w.bin_total = (u32*)(base + o_bin_total); w.bin_cursor = (u32*)(base + o_bin_cursor);
     w.bucket_count = (u32*)(base + o_bcount); w.bucket_cursor = (u32*)(base + o_bcursor);
     w.arena = base + o_arena;
@@ -344,8 +348,8 @@ struct PipProvider {
   const uint4* scalars; KAdd kadd;
   typedef PipDec Dec;
   // digit columns + pass-1 counts in one kernel
-  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, u32* block_counts, u32* bin_total, Dec& dec) const {
-    hipLaunchKernelGGL(k_pip_digits, dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total);
+  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, u32* block_counts, u32* bin_total, u32* err, Dec& dec) const {
+    hipLaunchKernelGGL(k_pip_digits, dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total, err);
     dec.dig16 = dig16;
     return LEMSM_OK;
   }
@@ -353,7 +357,7 @@ struct PipProvider {
 struct NegProvider {
   const uint8_t* digitsT;
   typedef NegDec Dec;
-  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t*, u32* block_counts, u32* bin_total, Dec& dec) const {
+  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t*, u32* block_counts, u32* bin_total, u32*, Dec& dec) const {
     dec.digitsT = digitsT;
     hipLaunchKernelGGL((k_count1<NegDec>), dim3(pl.w1 - pl.w0, pl.nblk1), dim3(256), 0, st, dec, pl, block_counts, bin_total);
     return LEMSM_OK;
@@ -398,7 +402,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
 
   typename Prov::Dec dec;
-  { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.block_counts, w.bin_total, dec); if (rcp) return rcp; }
+  { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.block_counts, w.bin_total, w.err, dec); if (rcp) return rcp; }
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
   hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
   hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
@@ -603,6 +607,14 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     HIPCHK(ctx, hipStreamSynchronize(s_acc));
     HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, s_tail));
     HIPCHK(ctx, hipStreamSynchronize(s_tail));
+    for (size_t gi = 0; gi < groups.size(); gi++) {   // non-canonical scalars (>= field order) are rejected, never bucketed
+      u32 ew[2] = {0, 0};
+      HIPCHK(ctx, hipMemcpy(ew, ws_base + groups[gi].off, 8, hipMemcpyDeviceToHost));
+      if (ew[0]) {
+        ctx->bad_index = s0 + (size_t)(~ew[1]);
+        return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
+      }
+    }
     for (size_t gi = 0; gi < groups.size(); gi++) {
       float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->evpool[3 * gi + 1], ctx->evpool[3 * gi + 2]));
       ctx->t_accum_ms += ms; ctx->n_accum++;
@@ -646,7 +658,7 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   if (wb > we || we > mp.W) return fail(ctx, LEMSM_ERR_BAD_ARG, "window range out of bounds");
   auto make_src = [&](size_t s0, u32) {
     PipProvider s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
-    memcpy(s.kadd.k, mp.kadd, 32); return s;
+    memcpy(s.kadd.k, mp.kadd, 32); memcpy(s.kadd.order, order_of(curve), 32); return s;
   };
   return run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, out);
 }
@@ -924,6 +936,8 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else return LEMSM_ERR_BAD_ARG;
   return LEMSM_OK;
 }
+
+size_t lemsm_last_bad_index(const lemsm_ctx* ctx) { return ctx ? ctx->bad_index : 0; }
 
 int lemsm_last_timing(const lemsm_ctx* ctx, double out[3]) {
   if (!ctx || !out) return LEMSM_ERR_BAD_ARG;

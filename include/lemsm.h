@@ -70,6 +70,9 @@ int lemsm_create(int device, lemsm_ctx** out);
 void lemsm_destroy(lemsm_ctx* ctx);
 const char* lemsm_strerror(int status);
 const char* lemsm_last_error(const lemsm_ctx* ctx);
+/* index of the offending scalar after a LEMSM_ERR_SCALAR_OUT_OF_RANGE from an entry that has no
+   bad_index parameter (lemsm_msm*: a scalar that is not a canonical field element) */
+size_t lemsm_last_bad_index(const lemsm_ctx* ctx);
 /* Tuning / test knobs: "window_bits" (0 = auto), "chunk" (entries per accumulate thread,
    0 = auto), "tile" (pass-2 tile entries, 0 = auto), "field" (0 = lazy radix-2^29 arithmetic, the default;
    1 = strict 32-bit-limb arithmetic, kept for A/B and as an in-library cross-check). */

@@ -200,6 +200,22 @@ def test_msm_skewed_buckets_all_windows_equal(fctx):
     assert canon(curve, out) == canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
 
 
+def test_msm_rejects_non_canonical_scalar(ctx):
+    """best_multiexp reads to_repr() bytes, which are always < order; a non-canonical scalar is
+    reported with its index instead of being bucketed"""
+    curve = pyref.BN254_G1
+    n = 300
+    pts = cref.gen_points(curve.cid, 1, 8); pts = np.tile(pts, (n // 8 + 1, 1))[:n]
+    sc = cref.gen_scalars(curve.cid, 2, n)
+    for bad in (curve.order, curve.order + 5, (1 << 256) - 1):
+        s2 = sc.copy(); s2[123] = np.frombuffer(int(bad).to_bytes(32, "little"), np.uint8)
+        with pytest.raises(api.ScalarOutOfRange) as ei:
+            ctx.msm(curve.cid, s2, pts)
+        assert ei.value.index == 123
+    s2 = sc.copy(); s2[7] = np.frombuffer(int(curve.order - 1).to_bytes(32, "little"), np.uint8)
+    assert canon(curve, ctx.msm(curve.cid, s2, pts)) == canon(curve, cref.best_multiexp(curve.cid, s2, pts, 4))
+
+
 def test_msm_length_mismatch(ctx):
     pts = cref.gen_points(0, 1, 3); sc = cref.gen_scalars(0, 2, 2)
     with pytest.raises(api.LengthMismatch, match="incompatible amount of coefficients"):
