@@ -641,12 +641,12 @@ host::pt window_sum(const host::pt* rec, u32 L) {
 }
 
 template <class P64>
-void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W x (L+1) */, u64 out[12]) {
+void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W window sums */, u64 out[12]) {
   typedef host::HG<P64> G;
   host::pt acc = G::identity();
   for (int w = (int)mp.W - 1; w >= 0; w--) {
     for (u32 k = 0; k < mp.c; k++) acc = G::dbl(acc);
-    acc = G::add(acc, window_sum<P64>(recs + (size_t)w * (mp.L + 1), mp.L));
+    acc = G::add(acc, recs[w]);
   }
   G::to_jacobian(acc, out);
 }
@@ -660,7 +660,13 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
     PipProvider s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
     memcpy(s.kadd.k, mp.kadd, 32); memcpy(s.kadd.order, order_of(curve), 32); return s;
   };
-  return run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, out);
+  std::vector<host::pt> recs;
+  int rc = run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, recs);
+  if (rc) return rc;
+  // this rank's share of the host tail: S_w = total + sum_l 2^l U_l for its own windows
+  out.resize(we - wb);
+  for (u32 w = 0; w < we - wb; w++) out[w] = window_sum<P64>(recs.data() + (size_t)w * (mp.L + 1), mp.L);
+  return LEMSM_OK;
 }
 
 int check_curve(lemsm_ctx* ctx, int curve) {
@@ -719,8 +725,11 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   // NegDec indexes digitsT[w * pl.n + j] with pl.n = slab size, so multi-slab inputs need the
   // full row stride: restrict the lhs path to one slab (n <= 2^24) for now.
   if (n > ((size_t)1 << MAX_SLAB_LOG)) return fail(ctx, LEMSM_ERR_BAD_ARG, "lhs path supports n <= 2^24 per call");
-  rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, out);
+  std::vector<host::pt> recs;
+  rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, recs);
   if (rc) return rc;
+  out.resize(pe - pb);
+  for (u32 w = 0; w < pe - pb; w++) out[w] = window_sum<P64>(recs.data() + (size_t)w * (lp.L + 1), lp.L);
   u32 err[2] = {0xffffffffu, 0};
   if (n) {
     HIPCHK(ctx, hipMemcpyAsync(err, dg.err, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -735,14 +744,14 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
 
 // carries: MSB-first Horner with multiplier -base over per-position sums (src/argument_witness_calc.rs:105-127)
 template <class P64>
-void lhs_combine_t(const LhsPlan& lp, const host::pt* recs /* d x (L+1), position (LSB-first) major */, u64 out_carry[12],
+void lhs_combine_t(const LhsPlan& lp, const host::pt* recs /* d per-position sums S_i, LSB-first position order */, u64 out_carry[12],
                    u64* out_carries) {
   typedef host::HG<P64> G;
   host::pt carry = G::identity();
   for (u32 it = 0; it < lp.d; it++) {
     u32 pos = lp.d - 1 - it;
     carry = G::mul_small(G::neg(carry), lp.base);                                  // :118
-    carry = G::add(carry, window_sum<P64>(recs + (size_t)pos * (lp.L + 1), lp.L)); // :120-125
+    carry = G::add(carry, recs[pos]);                                              // :120-125
     if (out_carries) G::to_jacobian(carry, out_carries + 12 * (size_t)it);
   }
   G::to_jacobian(carry, out_carry);
@@ -949,7 +958,7 @@ int lemsm_msm_plan(const lemsm_ctx* ctx, int curve, size_t n, uint32_t* num_wind
   if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
   MsmPlan mp = make_msm_plan(ctx, curve, n);
   if (num_windows) *num_windows = mp.W;
-  if (partial_bytes_per_window) *partial_bytes_per_window = (size_t)(mp.L + 1) * 128;
+  if (partial_bytes_per_window) *partial_bytes_per_window = 128;   // one XYZZ window sum
   return LEMSM_OK;
 }
 
@@ -969,7 +978,7 @@ int lemsm_msm_combine(const lemsm_ctx* ctx, int curve, size_t n, const uint8_t* 
   if (!partials || !out) return LEMSM_ERR_BAD_ARG;
   if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
   MsmPlan mp = make_msm_plan(ctx, curve, n);
-  std::vector<host::pt> recs((size_t)mp.W * (mp.L + 1));
+  std::vector<host::pt> recs((size_t)mp.W);
   memcpy(recs.data(), partials, recs.size() * sizeof(host::pt));
   if (curve == LEMSM_BN254_G1) msm_combine_t<host::FqParams64>(mp, recs.data(), out);
   else msm_combine_t<host::FrParams64>(mp, recs.data(), out);
@@ -1034,7 +1043,7 @@ int lemsm_lhs_plan(int curve, uint8_t base, uint32_t* num_positions, size_t* par
   if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
   LhsPlan lp; int rc = make_lhs_plan(curve, base, lp); if (rc) return rc;
   if (num_positions) *num_positions = lp.d;
-  if (partial_bytes) *partial_bytes = (size_t)(lp.L + 1) * 128;
+  if (partial_bytes) *partial_bytes = 128;
   return LEMSM_OK;
 }
 
@@ -1055,7 +1064,7 @@ int lemsm_lhs_combine(int curve, uint8_t base, const uint8_t* partials, uint64_t
   if (!partials || !out_carry) return LEMSM_ERR_BAD_ARG;
   if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
   LhsPlan lp; int rc = make_lhs_plan(curve, base, lp); if (rc) return rc;
-  std::vector<host::pt> recs((size_t)lp.d * (lp.L + 1));
+  std::vector<host::pt> recs((size_t)lp.d);
   memcpy(recs.data(), partials, recs.size() * sizeof(host::pt));
   if (curve == LEMSM_BN254_G1) lhs_combine_t<host::FqParams64>(lp, recs.data(), out_carry, out_carries);
   else lhs_combine_t<host::FrParams64>(lp, recs.data(), out_carry, out_carries);

@@ -1,12 +1,12 @@
 """Window-sharded MSM over the GPUs of one node (one process per GPU, torch.distributed).
 
 The path's only exchange step: every rank accumulates a contiguous range of Pippenger
-windows (or negabase digit positions) over ALL points, producing a small partial record per
-window ((L+1) XYZZ points, 128 B each -- 2 KiB per window at c = 16).  One all-gather of
+windows (or negabase digit positions) over ALL points and reduces each of them to its window sum
+S_w (one XYZZ point, 128 B).  One all-gather of
 those byte records over RCCL/xGMI (backend "nccl"; "gloo" on CPU for the tests) gives every
 rank all windows, and each rank runs the same host Horner tail.  Elliptic-curve addition is
 not an RCCL reduction operator, hence all-gather + local combine rather than (all-)reduce;
-the payload is a few tens of KiB, so the step is latency-bound and the xGMI link bandwidth
+the payload is 2 KiB for 16 windows, so the step is latency-bound and the xGMI link bandwidth
 is immaterial.
 
 The reference has no distributed code; this module is new (it replaces the role Rayon's

@@ -95,7 +95,9 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
 
 /* Window-sharded form (multi-GPU: each rank computes a range of Pippenger windows, ranks
    exchange the small partial records, everyone combines).  lemsm_msm_plan reports the number
-   of windows and the byte size of one window's partial record for an n-point MSM. */
+   of windows and the byte size of one window's partial record for an n-point MSM: the record is
+   the window's sum S_w = sum_k k * Bucket_{w,k} as one XYZZ point (x, y, zz, zzz; 4 x 32 bytes raw
+   Montgomery; zz == 0 is the identity). */
 int lemsm_msm_plan(const lemsm_ctx* ctx, int curve, size_t n, uint32_t* num_windows,
                    size_t* partial_bytes_per_window);
 int lemsm_msm_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars,

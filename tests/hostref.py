@@ -13,8 +13,10 @@ def msm_plan(curve, n):
     lib = _lib.load()
     w = ctypes.c_uint32(); b = ctypes.c_size_t()
     assert lib.lemsm_msm_plan(None, curve.cid, n, ctypes.byref(w), ctypes.byref(b)) == 0
-    L = b.value // 128 - 1
-    return w.value, L, b.value   # windows, pyramid levels (c = L + 1), record bytes
+    assert b.value == 128
+    # window bits c: the library's rule (choose_c in csrc/lemsm.hip): clamp(floor(log2 n) - 3, 3, 16)
+    c = max(3, min(16, n.bit_length() - 1 - 3))
+    return w.value, c - 1, b.value   # windows, L (c = L + 1), record bytes
 
 
 def xyzz_record(curve, pt):
@@ -26,15 +28,13 @@ def xyzz_record(curve, pt):
 
 
 def window_record(curve, buckets, L):
-    """buckets[j] (weight j+1), len <= 2^L -> [total, U_0..U_{L-1}] with U_l = sum_{j: bit l set} B_j"""
-    total = None
-    U = [None] * L
-    for j, bkt in enumerate(buckets):
-        total = curve.add(total, bkt)
-        for l in range(L):
-            if (j >> l) & 1:
-                U[l] = curve.add(U[l], bkt)
-    return b"".join(xyzz_record(curve, p) for p in [total] + U)
+    """buckets[j] (weight j+1) -> the window sum S = sum_j (j+1) * B_j as one XYZZ record (running sum)"""
+    running = None
+    acc = None
+    for bkt in reversed(buckets):
+        running = curve.add(running, bkt)
+        acc = curve.add(acc, running)
+    return xyzz_record(curve, acc)
 
 
 def msm_records(curve, scalars, pts, n_for_plan=None):
@@ -62,7 +62,8 @@ def lhs_plan(curve, base):
     lib = _lib.load()
     d = ctypes.c_uint32(); b = ctypes.c_size_t()
     assert lib.lemsm_lhs_plan(curve.cid, base, ctypes.byref(d), ctypes.byref(b)) == 0
-    return d.value, b.value // 128 - 1, b.value
+    assert b.value == 128
+    return d.value, 0, b.value
 
 
 def lhs_records(curve, scalars, pts, base):
