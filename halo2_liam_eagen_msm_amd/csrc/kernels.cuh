@@ -37,6 +37,7 @@ struct KAdd { u32 k[8]; u32 order[8]; };   // window offset constant K and the s
 // Signed-window Pippenger: s' = s + K with K = sum_{w<W-1} 2^(c-1) 2^(cw).  The raw c-bit windows
 // of s' are written window-major (dig16[(w-w0)*n + j], one coalesced 2-byte column per window) so
 // that the sort passes stream one window at a time.
+template <bool C16>
 __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ scalars, KAdd kadd, GroupPlan pl,
                                                     uint16_t* __restrict__ dig16, u32* __restrict__ block_counts,
                                                     u32* __restrict__ bin_total, u32* __restrict__ err) {
@@ -74,11 +75,24 @@ __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ sc
       u32 cy = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++) s[i] = __builtin_addc(s[i], kadd.k[i], cy, &cy);
-      for (u32 w = pl.w0; w < pl.w1; w++) {
-        u32 raw = extract_bits(s, w * pl.c, pl.c);
-        dig16[(size_t)(w - pl.w0) * pl.n + j] = (uint16_t)raw;
-        u32 bucket = (w + 1 < pl.W) ? (raw < half ? half - raw : raw - half) : raw;
-        if (bucket) atomicAdd(&hist[(w - pl.w0) * pl.BW + ((bucket - 1u) >> pl.LB)], 1u);
+      if (C16) {
+        // c = 16: window w is the (w & 1)-th half of limb w >> 1 -- static indexing, 2 instructions
+        // per window instead of the select chain of extract_bits (this kernel is VALU-heavy)
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+          if ((u32)w < pl.w0 || (u32)w >= pl.w1) continue;
+          u32 raw = (w & 1) ? (s[w >> 1] >> 16) : (s[w >> 1] & 0xffffu);
+          dig16[(size_t)((u32)w - pl.w0) * pl.n + j] = (uint16_t)raw;
+          u32 bucket = ((u32)w + 1 < pl.W) ? (raw < half ? half - raw : raw - half) : raw;
+          if (bucket) atomicAdd(&hist[((u32)w - pl.w0) * pl.BW + ((bucket - 1u) >> pl.LB)], 1u);
+        }
+      } else {
+        for (u32 w = pl.w0; w < pl.w1; w++) {
+          u32 raw = extract_bits(s, w * pl.c, pl.c);
+          dig16[(size_t)(w - pl.w0) * pl.n + j] = (uint16_t)raw;
+          u32 bucket = (w + 1 < pl.W) ? (raw < half ? half - raw : raw - half) : raw;
+          if (bucket) atomicAdd(&hist[(w - pl.w0) * pl.BW + ((bucket - 1u) >> pl.LB)], 1u);
+        }
       }
     }
   }

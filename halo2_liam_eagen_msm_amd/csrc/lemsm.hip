@@ -349,7 +349,10 @@ struct PipProvider {
   typedef PipDec Dec;
   // digit columns + pass-1 counts in one kernel
   int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, u32* block_counts, u32* bin_total, u32* err, Dec& dec) const {
-    hipLaunchKernelGGL(k_pip_digits, dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total, err);
+    if (pl.c == 16 && pl.W == 16)
+      hipLaunchKernelGGL((k_pip_digits<true>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total, err);
+    else
+      hipLaunchKernelGGL((k_pip_digits<false>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total, err);
     dec.dig16 = dig16;
     return LEMSM_OK;
   }
