@@ -116,8 +116,10 @@ struct HG {
     return r;
   }
   static pt mul_small(const pt& p, uint32_t k) {
-    pt acc = identity();
-    for (int i = 31; i >= 0; i--) { acc = dbl(acc); if ((k >> i) & 1) acc = add(acc, p); }
+    if (k == 0 || is_identity(p)) return identity();
+    int top = 31; while (!((k >> top) & 1)) top--;
+    pt acc = p;
+    for (int i = top - 1; i >= 0; i--) { acc = dbl(acc); if ((k >> i) & 1) acc = add(acc, p); }
     return acc;
   }
   // Jacobian (X', Y', Z') with x = X'/Z'^2, y = Y'/Z'^3:  Z' = ZZZ, X' = X*ZZ^2, Y' = Y*ZZZ^2

@@ -408,11 +408,18 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.block_counts, w.bin_total, w.err, dec); if (rcp) return rcp; }
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
   hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
-  hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
-  hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
-  hipLaunchKernelGGL(k_bucketscan, dim3((pl.nbins + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
-  hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info,
-                     w.bucket_start, w.bucket_cursor, w.sorted);
+  // pass 2 only where a bin holds more than one bucket (LB > 0); with <= 256 buckets per window
+  // (negabase digits) pass 1 already sorts exactly: bins are buckets
+  const u32* d_sorted = w.entries;
+  const u32* d_bstart = w.bin_start;
+  if (pl.LB > 0) {
+    hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
+    hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
+    hipLaunchKernelGGL(k_bucketscan, dim3((pl.nbins + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
+    hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info,
+                       w.bucket_start, w.bucket_cursor, w.sorted);
+    d_sorted = w.sorted; d_bstart = w.bucket_start;
+  }
 
   HIPCHK(ctx, hipEventRecord(ev_sorted, s_sort));
   st = s_acc;
@@ -424,11 +431,11 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     // register-budget variant of the accumulate kernel (lazy field: 2, 3 or 4 waves per SIMD)
     int wps = G::CONVERTED_DOMAIN ? (ctx->opt_accum_waves ? (int)ctx->opt_accum_waves : 3) : 4;
     if constexpr (G::CONVERTED_DOMAIN) {
-      if (wps == 2) hipLaunchKernelGGL((k_accum1<G, 2>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
-      else if (wps == 4) hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
-      else hipLaunchKernelGGL((k_accum1<G, 3>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      if (wps == 2) hipLaunchKernelGGL((k_accum1<G, 2>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      else if (wps == 4) hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      else hipLaunchKernelGGL((k_accum1<G, 3>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
     } else {
-      hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, w.sorted, w.bucket_start, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
     }
   }
   HIPCHK(ctx, hipEventRecord(ev_acc1, s_acc));
