@@ -443,17 +443,27 @@ __global__ __launch_bounds__(256) void k_negbase_digits(const uint4* __restrict_
   for (int i = 0; i < 8; i++) { h[2 * i] = s[i] & 0xffffu; h[2 * i + 1] = s[i] >> 16; }
   bool neg = false;
   const float rb = 1.0f / (float)base;
+  const u32 shift = (base & (base - 1u)) == 0 ? (u32)__builtin_ctz(base) : 0u;
   for (u32 i = 0; i < d; i++) {
-    // (q, rem) = divmod(|x|, base), most significant half first; partial dividends < 2^24
+    // (q, rem) = divmod(|x|, base)
     u32 rem = 0;
+    if (shift) {            // power-of-two base (the bench configuration, B = 16): a 2^shift-bit right shift
+      rem = h[0] & (base - 1u);
 #pragma unroll
-    for (int k = 15; k >= 0; k--) {
-      u32 cur = (rem << 16) | h[k];
-      u32 q = (u32)((float)cur * rb);
-      int r = (int)cur - (int)(q * base);
-      if (r < 0) { q--; r += (int)base; }
-      if (r >= (int)base) { q++; r -= (int)base; }
-      h[k] = q; rem = (u32)r;
+      for (int k = 0; k < 16; k++) {
+        u32 nxt = k < 15 ? h[k + 1] : 0u;
+        h[k] = ((h[k] | (nxt << 16)) >> shift) & 0xffffu;
+      }
+    } else {                // most significant half first; partial dividends < 2^24 are exact in fp32
+#pragma unroll
+      for (int k = 15; k >= 0; k--) {
+        u32 cur = (rem << 16) | h[k];
+        u32 q = (u32)((float)cur * rb);
+        int r = (int)cur - (int)(q * base);
+        if (r < 0) { q--; r += (int)base; }
+        if (r >= (int)base) { q++; r -= (int)base; }
+        h[k] = q; rem = (u32)r;
+      }
     }
     u32 digit;
     if (!neg) { digit = rem; neg = true; }
