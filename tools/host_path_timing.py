@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive timing of the host-pointer entry lemsm_msm (what a Rust caller with host buffers
+sees), next to the device-resident entry.  usage: host_path_timing.py LOGN"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from halo2_liam_eagen_msm_amd import Context, jacobian_to_canonical
+from bench import gen_scalars, ORDER
+
+logn = int(sys.argv[1]); n = 1 << logn
+ctx = Context(0)
+sc = gen_scalars(n, ORDER["bn254_g1"], 99)
+q = np.zeros(8, np.uint64); fp = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+q[:4] = np.frombuffer(((1 << 256) % fp).to_bytes(32, "little"), np.uint64); q[4:] = np.frombuffer(((2 << 256) % fp).to_bytes(32, "little"), np.uint64)
+dp = ctx.gen_walk(0, q, n)
+pts = dp.download(np.uint64).reshape(-1, 8).copy()
+ds = ctx.to_device(sc)
+ref = jacobian_to_canonical(0, ctx.msm_device(0, ds.ptr, dp.ptr, n))
+for it in range(4):
+    t0 = time.perf_counter(); out = ctx.msm(0, sc, pts); dt = time.perf_counter() - t0
+    assert jacobian_to_canonical(0, out) == ref
+    t1 = time.perf_counter(); ctx.msm_device(0, ds.ptr, dp.ptr, n); dd = time.perf_counter() - t1
+    print("2^%d: host-pointer entry %.1f ms (%.0f Mpairs/s, %.1f GB/s of input) | device-resident entry %.1f ms" % (logn, dt * 1e3, n / dt / 1e6, n * 96 / dt / 1e9, dd * 1e3), flush=True)
