@@ -6,7 +6,9 @@
 // product needs mad + addc (the 64-bit column accumulator overflows); with 29-bit limbs a
 // column of up to 27 products (< 2^58 each) fits a signed 64-bit accumulator, so a product is
 // ONE instruction and there is no conditional subtraction anywhere: ~215 instructions per
-// modular multiplication instead of ~370.
+// modular multiplication instead of ~370.  The products are generated (tools/gen_field29.py) as
+// one inline-asm block per column: left to itself hipcc hoists the products of later columns into
+// side accumulators (extra 64-bit adds, spills), and it pads every asm statement with an s_nop.
 //
 // Domain: kernels using this field work on x * 2^261 mod N.  The C ABI's raw-Montgomery
 // format is x * 2^256 (8 x u32): k_convert_points multiplies by 2^5 once per point per MSM,
@@ -40,15 +42,6 @@ struct Fr29Params {   // BN254 scalar field r
   static constexpr i32 ONE[9] = {0x0fffff57, 0x1ea70ab4, 0x052c068b, 0x17504f49, 0x0aa8075b, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836};
   static constexpr i32 C266[9] = {0x0fffead7, 0x1d5444f4, 0x04438aa5, 0x03b4d096, 0x134c84da, 0x0e92d304, 0x14cb95b3, 0x041b9d3d, 0x00058003};
 };
-
-// acc += a * b (signed 32 x 32 -> 64).  One instruction each; written as asm because hipcc
-// otherwise hoists products of later columns into side accumulators (extra 64-bit adds, spills).
-__device__ __forceinline__ void smad(i64& acc, i32 a, i32 b) {
-  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
-}
-__device__ __forceinline__ void smadc(i64& acc, i32 a, i32 b_const) {   // b wave-uniform (SGPR)
-  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(b_const) : "vcc");
-}
 
 template <class P>
 struct Field29 {

@@ -200,6 +200,42 @@ def test_msm_skewed_buckets_all_windows_equal(fctx):
     assert canon(curve, out) == canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
 
 
+@pytest.mark.parametrize("logn", [12, 18])
+def test_msm_extreme_skew_at_scale(fctx, logn):
+    """every scalar equal (one bucket per window holds all n entries: the edge-record levels do all
+    the merging), then additionally every point equal -- the reference's lhs_test shape, where every
+    addition of the first pass is a doubling (src/argument_witness_calc.rs:141-142)"""
+    ctx = fctx
+    curve = pyref.BN254_G1
+    n = 1 << logn
+    q = cref.gen_points(curve.cid, 500 + logn, 1)[0]
+    dp = ctx.gen_walk(curve.cid, q, n)
+    s1 = cref.gen_scalars(curve.cid, 501, 1)
+    sc = np.repeat(s1, n, axis=0)
+    ds = ctx.to_device(sc)
+    s_int = int.from_bytes(s1[0].tobytes(), "little")
+    k = s_int * (n * (n + 1) // 2) % curve.order                 # sum_i s * (i+1)
+    assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)) == canon(curve, cref.scalar_mul(curve.cid, k, q))
+    same = ctx.to_device(np.repeat(q.reshape(1, 8), n, axis=0))
+    k2 = s_int * n % curve.order
+    assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, same.ptr, n)) == canon(curve, cref.scalar_mul(curve.cid, k2, q))
+
+
+def test_msm_all_zero_scalars_and_all_identity_points(fctx):
+    ctx = fctx
+    curve = pyref.GRUMPKIN
+    n = 5000
+    pts = cref.gen_points(curve.cid, 600, 16); pts = np.tile(pts, (n // 16 + 1, 1))[:n]
+    zeros = np.zeros((n, 32), np.uint8)
+    assert canon(curve, ctx.msm(curve.cid, zeros, pts)) == bytes(64)
+    sc = cref.gen_scalars(curve.cid, 601, n)
+    assert canon(curve, ctx.msm(curve.cid, sc, np.zeros((n, 8), np.uint64))) == bytes(64)
+    # one real contribution among identities / zeros
+    sc2 = zeros.copy(); sc2[n - 1] = sc[n - 1]
+    exp = cref.scalar_mul(curve.cid, int.from_bytes(sc[n - 1].tobytes(), "little"), pts[n - 1])
+    assert canon(curve, ctx.msm(curve.cid, sc2, pts)) == canon(curve, exp)
+
+
 def test_msm_rejects_non_canonical_scalar(ctx):
     """best_multiexp reads to_repr() bytes, which are always < order; a non-canonical scalar is
     reported with its index instead of being bucketed"""
