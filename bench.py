@@ -165,11 +165,13 @@ def main():
         launches = max(launches, 1)
         accum_ms = acc_ms / launches
         # pairs one launch processes: all n pairs, for this rank's share of the windows
-        # algorithmic bytes of one launch = 96 B x n x (this rank's share of the windows)
-        achieved = BYTES_PER_PAIR * n / world / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+        # algorithmic bytes of one launch = 96 B x n x (the share of the windows that launch covers:
+        # 1/world of them per rank, split over the launches of one step when the windows run in groups)
+        launches_per_step = launches / args.steps
+        achieved = BYTES_PER_PAIR * n / world / launches_per_step / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.workload, curve, logn, world),
-                    "kernel": "k_accum1", "kernel_ms": round(accum_ms, 4), "pipeline_device_ms": round(tot_ms / args.steps, 4),
+                    "kernel": "k_accum1", "kernel_ms": round(accum_ms, 4), "launches_per_step": launches_per_step, "pipeline_device_ms": round(tot_ms / args.steps, 4),
                     "note": "integer-ALU-bound path: 96 algorithmic B/pair vs 8 TB/s HBM; see DESIGN.md for the VALU roofline"}
         out = {
             "metric": "BN254 G1 MSM scalar-point-pairs/s" if curve == "bn254_g1" else "Grumpkin MSM scalar-point-pairs/s",

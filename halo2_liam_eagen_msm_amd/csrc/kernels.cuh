@@ -37,9 +37,10 @@ struct KAdd { u32 k[8]; u32 order[8]; };   // window offset constant K and the s
 // Signed-window Pippenger: s' = s + K with K = sum_{w<W-1} 2^(c-1) 2^(cw).  The raw c-bit windows
 // of s' are written window-major (dig16[(w-w0)*n + j], one coalesced 2-byte column per window) so
 // that the sort passes stream one window at a time.
-template <bool C16>
+template <int MODE /* 0: any c <= 16, 1: c == 16, 2: c == 17 (sign bitmap beside the u16 column) */>
 __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ scalars, KAdd kadd, GroupPlan pl,
-                                                    uint16_t* __restrict__ dig16, u32* __restrict__ block_counts,
+                                                    uint16_t* __restrict__ dig16, unsigned long long* __restrict__ signbm,
+                                                    u32* __restrict__ block_counts,
                                                     u32* __restrict__ bin_total, u32* __restrict__ err) {
   // one block = one pass-1 range of spb scalars, all windows of the group: writes the digit
   // columns AND the per-(window, range, bin) counts the scatter needs (no separate count pass)
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ sc
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       u32 j = jb + 256u * u;
-      if (j >= j1) continue;
+      if (j >= j1) continue;   // wave-uniform for MODE 2's ballot: ranges and n are handled in whole waves (see below)
       u32 s[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
       // scalars must be canonical (< order), as PrimeField::to_repr() guarantees; anything else is
       // reported (LEMSM_ERR_SCALAR_OUT_OF_RANGE) and contributes nothing
@@ -75,7 +76,22 @@ __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ sc
       u32 cy = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++) s[i] = __builtin_addc(s[i], kadd.k[i], cy, &cy);
-      if (C16) {
+      if (MODE == 2) {
+        // c = 17: digit d = raw - 2^16 in [-2^16, 2^16) does not fit 16 bits with its sign.  The
+        // column stores v = |d| for d >= 0 and |d| - 1 for d < 0; the sign goes to a bitmap (one
+        // 64-bit word per wave and window, written from a ballot).  v = 0, sign = 0 is d = 0.
+#pragma unroll
+        for (int w = 0; w < 15; w++) {
+          if ((u32)w < pl.w0 || (u32)w >= pl.w1) continue;
+          u32 raw = extract_bits(s, 17u * w, 17u);
+          u32 sign = ((u32)w + 1 < pl.W && raw < 65536u) ? 1u : 0u;
+          u32 mag = ((u32)w + 1 < pl.W) ? (sign ? 65536u - raw : raw - 65536u) : raw;
+          dig16[(size_t)((u32)w - pl.w0) * pl.n + j] = (uint16_t)(sign ? mag - 1u : mag);
+          unsigned long long bal = __ballot(sign != 0);
+          if ((threadIdx.x & 63u) == 0) signbm[(size_t)((u32)w - pl.w0) * ((pl.n + 63) / 64) + (j >> 6)] = bal;
+          if (mag) atomicAdd(&hist[((u32)w - pl.w0) * pl.BW + ((mag - 1u) >> pl.LB)], 1u);
+        }
+      } else if (MODE == 1) {
         // c = 16: window w is the (w & 1)-th half of limb w >> 1 -- static indexing, 2 instructions
         // per window instead of the select chain of extract_bits (this kernel is VALU-heavy)
 #pragma unroll
@@ -108,8 +124,14 @@ __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ sc
 // decoders: bucket (0 = skip) and sign of scalar j in window w
 struct PipDec {
   const uint16_t* dig16;
+  const unsigned long long* signbm;   // c = 17 only (null otherwise)
   __device__ __forceinline__ void get(u32 j, u32 w, const GroupPlan& pl, u32& bucket, u32& sign) const {
     u32 raw = dig16[(size_t)(w - pl.w0) * pl.n + j];
+    if (signbm) {                      // c = 17 encoding, see k_pip_digits<2>
+      sign = (u32)(signbm[(size_t)(w - pl.w0) * ((pl.n + 63) / 64) + (j >> 6)] >> (j & 63u)) & 1u;
+      bucket = sign ? raw + 1u : raw;
+      return;
+    }
     const u32 half = 1u << (pl.c - 1);
     if (w + 1 < pl.W) {          // digit = raw - 2^(c-1), top window unsigned
       sign = raw < half ? 1u : 0u;
@@ -156,6 +178,7 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* total, u32* wsum 
 // consecutive lanes on consecutive addresses: scattered 4-byte stores cost ~16x write
 // amplification in HBM (the first version of this pass ran at 0.5 TB/s).
 // ------------------------------------------------------------------------------------
+static const u32 BW_MAX = 512;     // coarse bins per window (512 only for 17-bit windows, else <= 256)
 static const u32 STAGE = 4096;     // pass-1 range per block (more resident blocks hide its latency chain)
 static const u32 STAGE2 = 8192;    // pass-2 tile (longer runs per local bucket)
 
@@ -241,12 +264,12 @@ template <class Dec>
 __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
                                                   const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
                                                   u32* __restrict__ entries) {
-  __shared__ u32 lstart[257];
-  __shared__ u32 gbase[256];
-  __shared__ u32 lcur[256];
+  __shared__ u32 lstart[BW_MAX + 1];
+  __shared__ u32 gbase[BW_MAX];
+  __shared__ u32 lcur[BW_MAX];
   __shared__ u32 wsum[4];
   __shared__ u32 stage[STAGE];
-  __shared__ uint8_t sbin[STAGE];
+  __shared__ uint16_t sbin[STAGE];
   // grid = (windows, ranges): neighbouring blocks work on different windows, so the claim atomics
   // of concurrently running blocks spread over gw x BW addresses instead of hammering BW of them
   const u32 tid = threadIdx.x, wl = blockIdx.x, r = blockIdx.y, w = pl.w0 + wl;
@@ -263,13 +286,19 @@ __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u
     bk[k] = 0; sg[k] = 0;
     if (j < j1) dec.get(j, w, pl, bk[k], sg[k]);
   }
-  u32 cnt = tid < pl.BW ? block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + tid] : 0u;
-  u32 total;
-  u32 off = block_excl_scan_256(cnt, &total, wsum);
-  lstart[tid] = off;
-  if (tid == 255) lstart[256] = total;
-  gbase[tid] = cnt ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt) : 0u;
-  lcur[tid] = 0;
+  // up to BW_MAX = 512 bins per window: two bins per thread (tid and tid + 256)
+  const size_t crow = ((size_t)wl * pl.nblk1 + r) * pl.BW;
+  u32 cnt0 = tid < pl.BW ? block_counts[crow + tid] : 0u;
+  u32 cnt1 = tid + 256u < pl.BW ? block_counts[crow + tid + 256u] : 0u;
+  u32 total0, total1;
+  u32 off0 = block_excl_scan_256(cnt0, &total0, wsum);
+  u32 off1 = block_excl_scan_256(cnt1, &total1, wsum) + total0;
+  const u32 total = total0 + total1;
+  lstart[tid] = off0; lstart[tid + 256u] = off1;
+  if (tid == 255) lstart[BW_MAX] = total;
+  gbase[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) : 0u;
+  gbase[tid + 256u] = cnt1 ? bin_start[wl * pl.BW + tid + 256u] + atomicAdd(&bin_cursor[wl * pl.BW + tid + 256u], cnt1) : 0u;
+  lcur[tid] = 0; lcur[tid + 256u] = 0;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER; k++) {
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u
       u32 kk = bk[k] - 1u, b = kk >> pl.LB;
       u32 q = lstart[b] + atomicAdd(&lcur[b], 1u);
       stage[q] = j | ((kk & lmask) << 24) | (sg[k] << 31);
-      sbin[q] = (uint8_t)b;
+      sbin[q] = (uint16_t)b;
     }
   }
   __syncthreads();

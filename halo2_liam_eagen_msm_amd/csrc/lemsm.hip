@@ -143,8 +143,11 @@ struct MsmPlan {
 // window bits for an n-point MSM: 16 for large n (2-byte windows, 16 windows of 2^15 buckets
 // for 254-bit scalars: divisible by 1/2/4/8 GPUs); fewer for small n so buckets are not mostly empty.
 u32 choose_c(const lemsm_ctx* ctx, size_t n) {
-  if (ctx && ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 16) return (u32)ctx->opt_window_bits;
+  if (ctx && ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 17) return (u32)ctx->opt_window_bits;
   u32 lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
+  // (17-bit windows are supported through the option -- 15 windows of 2^16 buckets, 4 % less
+  // accumulation time at 2^24 -- but measured no faster end to end: two window groups double the
+  // latency-bound tail and the digit pass; profiles/r01/ab_c16_vs_c17.txt)
   int c = (int)lg - 3;
   if (c < 3) c = 3;
   if (c > 16) c = 16;
@@ -181,6 +184,10 @@ MsmPlan make_msm_plan(const lemsm_ctx* ctx, int curve, size_t n) {
     if (big || top > p.nb) fits = false;
     if (sh >= 256) { fits = true; }
     if (fits) { p.W = W; memcpy(p.kadd, K, 32); break; }
+  }
+  if (p.c == 17 && p.W != 15) {   // the 17-bit digit kernel is written for 15 windows (254-bit orders)
+    lemsm_ctx tmp_opts; tmp_opts.opt_window_bits = 16;
+    return make_msm_plan(&tmp_opts, curve, n);
   }
   return p;
 }
@@ -255,6 +262,7 @@ struct GroupWs {
   u32* bucket_count; u32* bucket_cursor; u32* bucket_start;
   u32* block_counts;
   uint16_t* dig16;
+  unsigned long long* signbm;
   uint4* tile_info;
   u32* entries; u32* sorted;
   u32* rec_key_a; char* rec_pt_a; u32* rec_key_b; char* rec_pt_b;
@@ -280,6 +288,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 4);
   size_t o_dig = take(pl.c ? (size_t)pl.n * (pl.w1 - pl.w0) * 2 + 16 : 16);
   size_t o_tinfo = take((size_t)pl.max_tiles * 16 + 16);
+  size_t o_sbm = take(pl.c == 17 ? (size_t)(pl.w1 - pl.w0) * ((pl.n + 63) / 64) * 8 + 16 : 16);
   size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
   size_t o_entries = take(Mmax * 4 + 16), o_sorted = take(Mmax * 4 + 16);
   size_t R1 = 2 * (size_t)pl.nthr1;
@@ -292,7 +301,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
     w.bucket_count = (u32*)(base + o_bcount); w.bucket_cursor = (u32*)(base + o_bcursor);
     w.arena = base + o_arena;
     w.bin_start = (u32*)(base + o_bin_start); w.tile_prefix = (u32*)(base + o_tile_prefix); w.meta = (u32*)(base + o_meta);
-    w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc); w.dig16 = (uint16_t*)(base + o_dig); w.tile_info = (uint4*)(base + o_tinfo);
+    w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc); w.dig16 = (uint16_t*)(base + o_dig); w.tile_info = (uint4*)(base + o_tinfo); w.signbm = (unsigned long long*)(base + o_sbm);
     w.entries = (u32*)(base + o_entries); w.sorted = (u32*)(base + o_sorted);
     w.rec_key_a = (u32*)(base + o_rka); w.rec_pt_a = base + o_rpa; w.rec_key_b = (u32*)(base + o_rkb); w.rec_pt_b = base + o_rpb;
   }
@@ -304,7 +313,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   GroupPlan g; memset(&g, 0, sizeof g);
   g.n = n; g.c = c; g.nb = nb; g.W = W; g.w0 = w0; g.w1 = w1; g.d = d;
   u32 LB = 0;
-  while (((nb + (1u << LB) - 1) >> LB) > 256) LB++;     // <= 256 coarse bins per window
+  while (((nb + (1u << LB) - 1) >> LB) > 256 && LB < MAX_LB) LB++;   // <= 256 coarse bins per window (512 at nb = 2^16)
   g.LB = LB;
   g.BW = (nb + (1u << LB) - 1) >> LB;
   g.nbw = g.BW << LB;
@@ -337,7 +346,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
 // max windows per group: (w1-w0) * BW <= MAX_BINS
 u32 max_group_windows(u32 nb) {
   u32 LB = 0;
-  while (((nb + (1u << LB) - 1) >> LB) > 256) LB++;
+  while (((nb + (1u << LB) - 1) >> LB) > 256 && LB < MAX_LB) LB++;
   u32 BW = (nb + (1u << LB) - 1) >> LB;
   u32 cap = MAX_BINS / BW;
   return cap == 0 ? 1 : cap;
@@ -348,19 +357,23 @@ struct PipProvider {
   const uint4* scalars; KAdd kadd;
   typedef PipDec Dec;
   // digit columns + pass-1 counts in one kernel
-  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, u32* block_counts, u32* bin_total, u32* err, Dec& dec) const {
-    if (pl.c == 16 && pl.W == 16)
-      hipLaunchKernelGGL((k_pip_digits<true>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total, err);
+  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t* dig16, unsigned long long* signbm, u32* block_counts,
+              u32* bin_total, u32* err, Dec& dec) const {
+    dec.dig16 = dig16; dec.signbm = nullptr;
+    if (pl.c == 17) {
+      dec.signbm = signbm;
+      hipLaunchKernelGGL((k_pip_digits<2>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+    } else if (pl.c == 16 && pl.W == 16)
+      hipLaunchKernelGGL((k_pip_digits<1>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
     else
-      hipLaunchKernelGGL((k_pip_digits<false>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, block_counts, bin_total, err);
-    dec.dig16 = dig16;
+      hipLaunchKernelGGL((k_pip_digits<0>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
     return LEMSM_OK;
   }
 };
 struct NegProvider {
   const uint8_t* digitsT;
   typedef NegDec Dec;
-  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t*, u32* block_counts, u32* bin_total, u32*, Dec& dec) const {
+  int prepare(lemsm_ctx*, hipStream_t st, const GroupPlan& pl, uint16_t*, unsigned long long*, u32* block_counts, u32* bin_total, u32*, Dec& dec) const {
     dec.digitsT = digitsT;
     hipLaunchKernelGGL((k_count1<NegDec>), dim3(pl.w1 - pl.w0, pl.nblk1), dim3(256), 0, st, dec, pl, block_counts, bin_total);
     return LEMSM_OK;
@@ -405,7 +418,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
 
   typename Prov::Dec dec;
-  { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.block_counts, w.bin_total, w.err, dec); if (rcp) return rcp; }
+  { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.signbm, w.block_counts, w.bin_total, w.err, dec); if (rcp) return rcp; }
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
   hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
   // pass 2 only where a bin holds more than one bucket (LB > 0); with <= 256 buckets per window
@@ -591,7 +604,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e);
   }
   hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream, s_tail = ctx->stream_tail;
-  if (groups.size() == 1) { s_sort = s_acc; s_tail = s_acc; }   // one queue: exact event timing, no cross-queue waits
+  if (ctx->opt_groups <= 1) { s_sort = s_acc; s_tail = s_acc; }   // one queue unless pipelining was asked for: exact event timing
   HIPCHK(ctx, hipStreamSynchronize(s_acc));   // inputs staged / digits produced on the main stream are complete
   std::vector<host::pt> tmp;
   std::vector<char> raw((size_t)nw * (L + 1) * ptb);
@@ -946,7 +959,7 @@ const char* lemsm_last_error(const lemsm_ctx* ctx) { return ctx ? ctx->last_erro
 
 int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   if (!ctx || !name) return LEMSM_ERR_BAD_ARG;
-  if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 16)) return LEMSM_ERR_BAD_ARG; ctx->opt_window_bits = value; }
+  if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 17)) return LEMSM_ERR_BAD_ARG; ctx->opt_window_bits = value; }
   else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }

@@ -15,7 +15,8 @@ def msm_plan(curve, n):
     assert lib.lemsm_msm_plan(None, curve.cid, n, ctypes.byref(w), ctypes.byref(b)) == 0
     assert b.value == 128
     # window bits c: the library's rule (choose_c in csrc/lemsm.hip): clamp(floor(log2 n) - 3, 3, 16)
-    c = max(3, min(16, n.bit_length() - 1 - 3))
+    lg = n.bit_length() - 1
+    c = max(3, min(16, lg - 3))
     return w.value, c - 1, b.value   # windows, L (c = L + 1), record bytes
 
 

@@ -140,7 +140,7 @@ def test_msm_matches_oracle(fctx, curve, n):
     assert canon(curve, out) == canon(curve, exp)
 
 
-@pytest.mark.parametrize("c_bits", [2, 3, 5, 8, 11, 13, 16])
+@pytest.mark.parametrize("c_bits", [2, 3, 5, 8, 11, 13, 16, 17])
 @pytest.mark.parametrize("chunk", [1, 7, 64])
 def test_msm_window_and_chunk_sweep(fctx, c_bits, chunk):
     ctx = fctx
@@ -406,14 +406,15 @@ def test_msm_ragged_sizes_around_block_and_tile_boundaries(ctx, n):
     ds = ctx.to_device(sc)
     exp = canon(curve, cref.scalar_mul(curve.cid, cref.walk_dot(curve.cid, sc), q))
     assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)) == exp
-    ctx.set_option("window_bits", 16)
-    try:
-        out1 = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
-        out2 = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
-    finally:
-        ctx.set_option("window_bits", 0)
-    assert canon(curve, out1) == exp
-    assert canon(curve, out2) == exp          # repeatable (atomics reorder the summation, never the group element)
+    for cb in (16, 17):
+        ctx.set_option("window_bits", cb)
+        try:
+            out1 = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+            out2 = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+        finally:
+            ctx.set_option("window_bits", 0)
+        assert canon(curve, out1) == exp, cb
+        assert canon(curve, out2) == exp, cb  # repeatable (atomics reorder the summation, never the group element)
 
 
 def test_lhs_large_walk_relation(ctx):

@@ -31,7 +31,7 @@ def test_msm_plan_windows():
         for n in (1, 100, 1 << 12, 1 << 20, 1 << 24, 1 << 26):
             W, L, rec = hostref.msm_plan(c, n)
             cbits = L + 1
-            assert rec == 128 and 3 <= cbits <= 16
+            assert rec == 128 and 3 <= cbits <= 17
             K = sum((1 << (cbits - 1)) << (cbits * w) for w in range(W - 1))
             assert ((c.order - 1 + K) >> (cbits * (W - 1))) <= (1 << (cbits - 1))   # top window fits the buckets
             assert (c.order - 1 + K) >> (cbits * W) == 0
