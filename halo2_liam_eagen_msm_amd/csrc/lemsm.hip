@@ -57,6 +57,7 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+
 // bucket-reduction pyramid: per step a list of pairwise-add tasks (kernels_ec.cuh)
 struct PyrPlan {
   std::vector<std::vector<PyrTask>> steps;   // steps[s-1] for s = 1..L
@@ -66,6 +67,9 @@ struct PyrPlan {
 struct PyrCacheEntry { DevBuf buf; PyrPlan pp; };   // task tables resident on the device
 
 }  // namespace
+
+// host-pointer entries: where one call's inputs live on the host and where their slabs are staged in HBM
+struct HostStage { const uint8_t* h_scalars; const void* h_points; char* d_scalars; char* d_points; };
 
 struct lemsm_ctx {
   int device = 0;
@@ -79,7 +83,8 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0;
+  const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   size_t bad_index = 0;
   std::map<std::vector<u32>, PyrCacheEntry> pyr_cache;   // keyed by (NBpad, nb, nbw, nbp, L, gw)
@@ -571,7 +576,21 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   u32 nw = we - wb;
   host_out.assign((size_t)nw * (L + 1), HGp::identity());
   if (n == 0 || nw == 0) return LEMSM_OK;
-  const size_t SLAB = (size_t)1 << MAX_SLAB_LOG;
+  // Slabs of points: every slab runs the whole pipeline and the per-window records of the slabs
+  // are added on the host.  Device-resident inputs use the largest slab the 32-bit entry format
+  // allows; host-pointer entries (ctx->host_stage) use small slabs so that the PCIe upload of slab
+  // k+1 (upload queue, host blocked in the copy) overlaps the kernels of slab k (main queue).
+  const HostStage* hs = ctx->host_stage;
+  u32 slab_log = ctx->opt_slab_bits ? (u32)ctx->opt_slab_bits : MAX_SLAB_LOG;
+  if (hs) {
+    // auto: a quarter of the input per slab, between 2^19 (below that the fixed ~0.5 ms tail of a
+    // slab costs more than the overlap hides) and 2^21 (measured best at 2^24: profiles/r01/host_pointer_*)
+    u32 lg = 0; while (((size_t)2 << lg) <= n) lg++;   // floor(log2 n)
+    u32 auto_log = std::min(21u, std::max(19u, lg >= 2 ? lg - 2 : 0u));
+    slab_log = std::min<u32>(MAX_SLAB_LOG, ctx->opt_host_slab_bits ? (u32)ctx->opt_host_slab_bits : auto_log);
+  }
+  const size_t SLAB = (size_t)1 << slab_log;
+  const size_t nslabs = (n + SLAB - 1) / SLAB;
   u32 gmax = max_group_windows(nb);
   const size_t ptb = G::PT_BYTES;
   // Window groups of this call.  Default: as few as the bin limit allows (one at c = 16).  With
@@ -593,64 +612,88 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
       ws_total += align_up(group_ws_bytes(pl, nbp, L, ptb), 256);
     }
   }
-  size_t out_bytes = align_up((size_t)nw * (L + 1) * ptb, 256);
+  const size_t ng = groups.size();
+  const size_t out_slab = align_up((size_t)nw * (L + 1) * ptb, 256);   // one slab's records
+  const size_t err_bytes = align_up(nslabs * ng * 8, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
-  int rc = reserve(ctx, ctx->ws, ws_total + out_bytes + conv_bytes + 4096);
+  int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nslabs + err_bytes + 4096);
   if (rc) return rc;
   char* ws_base = (char*)ctx->ws.p;
-  char* d_out = ws_base + ws_total;
-  char* d_conv = d_out + out_bytes;
-  while (ctx->evpool.size() < 3 * groups.size()) {
+  char* d_conv = ws_base + ws_total;
+  char* d_out = d_conv + conv_bytes;
+  char* d_err = d_out + out_slab * nslabs;
+  while (ctx->evpool.size() < 3 * ng * nslabs + (hs ? nslabs : 0)) {
     hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e);
   }
+  hipEvent_t* ev_up = ctx->evpool.data() + 3 * ng * nslabs;
   hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream, s_tail = ctx->stream_tail;
-  if (ctx->opt_groups <= 1) { s_sort = s_acc; s_tail = s_acc; }   // one queue unless pipelining was asked for: exact event timing
+  const bool one_queue = ctx->opt_groups <= 1;
+  if (one_queue) { s_sort = s_acc; s_tail = s_acc; }   // one queue unless pipelining was asked for: exact event timing
+  hipStream_t s_up = ctx->stream_sort;                 // upload queue of the host-pointer path (one_queue is forced there)
+  if (hs && !one_queue) return fail(ctx, LEMSM_ERR_BAD_ARG, "option groups > 1 is only available on the device-pointer entries");
   HIPCHK(ctx, hipStreamSynchronize(s_acc));   // inputs staged / digits produced on the main stream are complete
-  std::vector<host::pt> tmp;
-  std::vector<char> raw((size_t)nw * (L + 1) * ptb);
-  HIPCHK(ctx, hipEventRecord(ctx->ev[0], s_sort));
+  HIPCHK(ctx, hipEventRecord(ctx->ev[0], s_acc));
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
-  for (size_t s0 = 0; s0 < n; s0 += SLAB) {
+  for (size_t k = 0; k < nslabs; k++) {
+    const size_t s0 = k * SLAB;
     u32 sn = (u32)std::min(SLAB, n - s0);
+    if (hs) {
+      HIPCHK(ctx, hipMemcpyAsync(hs->d_scalars + s0 * 32, hs->h_scalars + s0 * 32, (size_t)sn * 32, hipMemcpyHostToDevice, s_up));
+      HIPCHK(ctx, hipMemcpyAsync(hs->d_points + s0 * 64, (const char*)hs->h_points + s0 * 64, (size_t)sn * 64, hipMemcpyHostToDevice, s_up));
+      HIPCHK(ctx, hipEventRecord(ev_up[k], s_up));
+      HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_up[k], 0));
+    }
     const char* pts = (const char*)d_points + s0 * 64;
     if constexpr (G::CONVERTED_DOMAIN) {
       hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, s_acc, (const uint4*)pts, (uint4*)d_conv, sn);
       pts = d_conv;
     }
-    for (size_t gi = 0; gi < groups.size(); gi++) {
+    for (size_t gi = 0; gi < ng; gi++) {
       const Grp& gr = groups[gi];
       GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, gr.g0, gr.g1, d);
       auto src = make_src(s0, sn);
-      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base + gr.off, d_out + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
-                        s_sort, s_acc, s_tail, ctx->evpool[3 * gi], ctx->evpool[3 * gi + 1], ctx->evpool[3 * gi + 2]);
+      hipEvent_t* ev = ctx->evpool.data() + 3 * (k * ng + gi);
+      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
+                        s_sort, s_acc, s_tail, ev[0], ev[1], ev[2]);
       if (rc) return rc;
+      // the group's non-canonical-scalar flag (first 8 bytes of its workspace) survives the workspace reuse
+      HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * 8, ws_base + gr.off, 8, hipMemcpyDeviceToDevice, s_tail));
     }
-    // drain: everything of this slab (the workspace is reused by the next slab)
-    HIPCHK(ctx, hipStreamSynchronize(s_sort));
-    HIPCHK(ctx, hipStreamSynchronize(s_acc));
-    HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, s_tail));
-    HIPCHK(ctx, hipStreamSynchronize(s_tail));
-    for (size_t gi = 0; gi < groups.size(); gi++) {   // non-canonical scalars (>= field order) are rejected, never bucketed
-      u32 ew[2] = {0, 0};
-      HIPCHK(ctx, hipMemcpy(ew, ws_base + groups[gi].off, 8, hipMemcpyDeviceToHost));
-      if (ew[0]) {
-        ctx->bad_index = s0 + (size_t)(~ew[1]);
-        return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
-      }
+    if (!one_queue) {   // three queues share one workspace: drain before the next slab reuses it
+      HIPCHK(ctx, hipStreamSynchronize(s_sort));
+      HIPCHK(ctx, hipStreamSynchronize(s_acc));
+      HIPCHK(ctx, hipStreamSynchronize(s_tail));
     }
-    for (size_t gi = 0; gi < groups.size(); gi++) {
-      float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->evpool[3 * gi + 1], ctx->evpool[3 * gi + 2]));
-      ctx->t_accum_ms += ms; ctx->n_accum++;
-    }
-    from_device_records<P64, G>(raw, tmp);
-    if (s0 == 0) host_out = tmp;
-    else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = HGp::add(host_out[i], tmp[i]);
+    // one queue: the slabs' kernels are stream-ordered, so the workspace is reused without a drain
   }
-  hipStream_t st = s_tail;
-  HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+  std::vector<char> raw(out_slab * nslabs);
+  std::vector<u32> errw(nslabs * ng * 2);
+  HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, s_tail));
+  HIPCHK(ctx, hipMemcpyAsync(errw.data(), d_err, errw.size() * 4, hipMemcpyDeviceToHost, s_tail));
+  HIPCHK(ctx, hipEventRecord(ctx->ev[1], s_tail));
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
   float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
   ctx->t_total_ms = ms;
+  for (size_t k = 0; k < nslabs; k++)   // non-canonical scalars (>= field order) are rejected, never bucketed
+    for (size_t gi = 0; gi < ng; gi++) {
+      const u32* ew = errw.data() + (k * ng + gi) * 2;
+      if (ew[0]) {
+        ctx->bad_index = k * SLAB + (size_t)(~ew[1]);
+        return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
+      }
+    }
+  for (size_t i = 0; i < nslabs * ng; i++) {
+    float a = 0; HIPCHK(ctx, hipEventElapsedTime(&a, ctx->evpool[3 * i + 1], ctx->evpool[3 * i + 2]));
+    ctx->t_accum_ms += a; ctx->n_accum++;
+  }
+  std::vector<host::pt> tmp;
+  std::vector<char> one((size_t)nw * (L + 1) * ptb);
+  for (size_t k = 0; k < nslabs; k++) {
+    memcpy(one.data(), raw.data() + k * out_slab, one.size());
+    from_device_records<P64, G>(one, tmp);
+    if (k == 0) host_out = tmp;
+    else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = HGp::add(host_out[i], tmp[i]);
+  }
   return LEMSM_OK;
 }
 
@@ -963,6 +1006,8 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
+  else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
+  else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }
   else if (!strcmp(name, "field")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_field = value; }
   else return LEMSM_ERR_BAD_ARG;
@@ -1027,9 +1072,14 @@ int lemsm_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t*
   int rc = check_curve(ctx, curve); if (rc) return rc;
   if (n == 0) { memset(out, 0, 96); return LEMSM_OK; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  rc = stage(ctx, ctx->in_s, scalars, n * 32); if (rc) return rc;
-  rc = stage(ctx, ctx->in_p, points, n * 64); if (rc) return rc;
-  return lemsm_msm_device(ctx, curve, ctx->in_s.p, ctx->in_p.p, n, out);
+  // staged slab by slab inside run_windows, the upload of one slab overlapping the kernels of the previous one
+  rc = reserve(ctx, ctx->in_s, n * 32); if (rc) return rc;
+  rc = reserve(ctx, ctx->in_p, n * 64); if (rc) return rc;
+  HostStage hs{scalars, points, (char*)ctx->in_s.p, (char*)ctx->in_p.p};
+  ctx->host_stage = &hs;
+  rc = lemsm_msm_device(ctx, curve, ctx->in_s.p, ctx->in_p.p, n, out);
+  ctx->host_stage = nullptr;
+  return rc;
 }
 int lemsm_msm_bn254_g1(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, size_t n, uint64_t out[12]) { return lemsm_msm(ctx, LEMSM_BN254_G1, s, p, n, out); }
 int lemsm_msm_grumpkin(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, size_t n, uint64_t out[12]) { return lemsm_msm(ctx, LEMSM_GRUMPKIN, s, p, n, out); }

@@ -75,7 +75,12 @@ const char* lemsm_last_error(const lemsm_ctx* ctx);
 size_t lemsm_last_bad_index(const lemsm_ctx* ctx);
 /* Tuning / test knobs: "window_bits" (0 = auto), "chunk" (entries per accumulate thread,
    0 = auto), "tile" (pass-2 tile entries, 0 = auto), "field" (0 = lazy radix-2^29 arithmetic, the default;
-   1 = strict 32-bit-limb arithmetic, kept for A/B and as an in-library cross-check). */
+   1 = strict 32-bit-limb arithmetic, kept for A/B and as an in-library cross-check),
+   "accum_waves" (2..4 waves per SIMD of the accumulate kernel, 0 = auto), "groups" (window groups
+   pipelined over three queues, device-pointer entries only; 0 = one group),
+   "host_slab_bits" (host-pointer entries: log2 of the slab of pairs uploaded while the previous
+   slab is being accumulated; 0 = auto = 21), "slab_bits" (device-pointer entries: log2 of the
+   slab of pairs one pass of the pipeline covers; 0 = auto = 24, smaller values are a test knob). */
 int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value);
 /* Device-time (ms, from HIP events on the context's stream) of the last MSM call: whole
    pipeline in [0], the dominant accumulate kernel in [1], its launch count in [2]. */

@@ -252,6 +252,68 @@ def test_msm_rejects_non_canonical_scalar(ctx):
     assert canon(curve, ctx.msm(curve.cid, s2, pts)) == canon(curve, cref.best_multiexp(curve.cid, s2, pts, 4))
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,slab_bits", [(20000, 12), (4096 * 3, 12), (4097, 12), (70001, 14)])
+def test_msm_host_entry_slab_pipeline(fctx, curve, n, slab_bits):
+    """the host-pointer entry uploads slab k+1 while slab k is accumulated; several slabs with a
+    ragged last one give the oracle's result and the device-pointer entry's"""
+    ctx = fctx
+    ctx.set_option("host_slab_bits", slab_bits)
+    try:
+        pts = cref.gen_points(curve.cid, 7000 + n, n)
+        sc = cref.gen_scalars(curve.cid, 8000 + n, n)
+        out = ctx.msm(curve.cid, sc, pts)
+        assert canon(curve, out) == canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+        ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+        assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)) == canon(curve, out)
+    finally:
+        ctx.set_option("host_slab_bits", 0)
+
+
+@pytest.mark.parametrize("groups", [0, 3])
+def test_msm_device_entry_multi_slab(fctx, groups):
+    """n above the slab size (2^24 pairs by default; shrunk here): slabs run back to back on one
+    queue reusing one workspace (or drained per slab with pipelined groups) and add up exactly"""
+    ctx = fctx
+    curve = pyref.BN254_G1
+    n = 5 * 4096 + 123
+    pts = cref.gen_points(curve.cid, 31, n); sc = cref.gen_scalars(curve.cid, 32, n)
+    exp = canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    ctx.set_option("slab_bits", 12); ctx.set_option("groups", groups)
+    try:
+        assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)) == exp
+        s2 = sc.copy(); s2[4 * 4096 + 5] = np.frombuffer(int(curve.order).to_bytes(32, "little"), np.uint8)
+        d2 = ctx.to_device(s2)
+        with pytest.raises(api.ScalarOutOfRange) as ei:
+            ctx.msm_device(curve.cid, d2.ptr, dp.ptr, n)
+        assert ei.value.index == 4 * 4096 + 5
+    finally:
+        ctx.set_option("slab_bits", 0); ctx.set_option("groups", 0)
+
+
+def test_msm_host_entry_bad_scalar_in_later_slab(ctx):
+    curve = pyref.BN254_G1
+    n = 3 * 4096 + 17
+    ctx.set_option("host_slab_bits", 12)
+    try:
+        pts = cref.gen_points(curve.cid, 1, 8); pts = np.tile(pts, (n // 8 + 1, 1))[:n]
+        sc = cref.gen_scalars(curve.cid, 2, n)
+        for idx in (5, 4096, 2 * 4096 + 9, n - 1):
+            s2 = sc.copy(); s2[idx] = np.frombuffer(int(curve.order).to_bytes(32, "little"), np.uint8)
+            with pytest.raises(api.ScalarOutOfRange) as ei:
+                ctx.msm(curve.cid, s2, pts)
+            assert ei.value.index == idx
+        s2 = sc.copy()
+        for idx in (2 * 4096 + 9, 4100):     # two offenders: the first one is reported
+            s2[idx] = np.frombuffer(int(curve.order + 1).to_bytes(32, "little"), np.uint8)
+        with pytest.raises(api.ScalarOutOfRange) as ei:
+            ctx.msm(curve.cid, s2, pts)
+        assert ei.value.index == 4100
+    finally:
+        ctx.set_option("host_slab_bits", 0)
+
+
 def test_msm_length_mismatch(ctx):
     pts = cref.gen_points(0, 1, 3); sc = cref.gen_scalars(0, 2, 2)
     with pytest.raises(api.LengthMismatch, match="incompatible amount of coefficients"):
