@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--base", type=int, default=16)
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 of the cpu_baseline sample size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharding", choices=["windows", "points"], default="windows",
+                    help="N > 1 partition of the MSM: Pippenger windows (north star, default) or pairs (SURVEY 8e alternative)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +134,8 @@ def main():
         if args.workload == "msm":
             if world == 1:
                 return ctx.msm_device(cid, d_scalars.ptr, d_points.ptr, n)
+            if args.sharding == "points":
+                return ldist.sharded_msm_by_points(ctx, cid, d_scalars.ptr, d_points.ptr, n, world, rank, coll_dev)
             return ldist.sharded_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, world, rank, coll_dev)
         if world == 1:
             return ctx.lhs_msm_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True)[0]
@@ -195,7 +199,7 @@ def main():
             "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
             "config": {"workload": ("%s MSM, 2^%d points, full-width scalars" % (curve, logn)) if args.workload == "msm"
                        else ("%s compute_lhs_witness MSM core, 2^%d points, negabase B=%d (w=4), half-width scalars" % (curve, logn, args.base)),
-                       "n": n, "curve": curve, "sharding": "pippenger-window x%d" % world, "bit_exact": True,
+                       "n": n, "curve": curve, "sharding": ("pairs x%d" if (args.sharding == "points" and args.workload == "msm") else "pippenger-window x%d") % world, "bit_exact": True,
                        "input_gen_s": round(t_in, 2)},
             "roofline": roofline,
         }

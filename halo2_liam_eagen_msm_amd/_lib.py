@@ -37,7 +37,7 @@ SYMBOLS = [
     "lemsm_lhs_msm", "lemsm_lhs_msm_grumpkin", "lemsm_lhs_msm_bn254_g1", "lemsm_lhs_msm_device",
     "lemsm_lhs_plan", "lemsm_lhs_partial_device", "lemsm_lhs_combine",
     "lemsm_precompute_multiplicities", "lemsm_precompute_multiplicities_affine",
-    "lemsm_jacobian_to_canonical",
+    "lemsm_jacobian_to_canonical", "lemsm_jacobian_sum",
     "lemsm_device_alloc", "lemsm_device_free", "lemsm_device_upload", "lemsm_device_download",
     "lemsm_device_gen_walk",
     "lemsm_debug_montmul", "lemsm_debug_fieldop", "lemsm_debug_pointop",
@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
         "lemsm_precompute_multiplicities": (i, [vp, i, u64p, sz, ctypes.c_uint8, u64p]),
         "lemsm_precompute_multiplicities_affine": (i, [vp, i, u64p, sz, ctypes.c_uint8, u64p]),
         "lemsm_jacobian_to_canonical": (i, [i, u64p, u8p]),
+        "lemsm_jacobian_sum": (i, [i, u64p, sz, u64p]),
         "lemsm_device_alloc": (i, [vp, sz, ctypes.POINTER(vp)]),
         "lemsm_device_free": (i, [vp, vp]),
         "lemsm_device_upload": (i, [vp, vp, vp, sz]),

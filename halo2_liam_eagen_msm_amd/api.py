@@ -312,6 +312,17 @@ def jacobian_to_canonical(curve, jac) -> bytes:
     return out.tobytes()
 
 
+def jacobian_sum(curve, jacs) -> np.ndarray:
+    """Host-side sum of Jacobian points (the combine step of a point-sharded MSM; the fold over
+    per-thread results inside halo2's best_multiexp)."""
+    jacs = np.ascontiguousarray(jacs, np.uint64).reshape(-1, 12)
+    out = np.zeros(12, np.uint64)
+    rc = _lib.load().lemsm_jacobian_sum(_curve_id(curve), _ptr(jacs), jacs.shape[0], _ptr(out))
+    if rc:
+        raise LemsmError(rc, "jacobian_sum")
+    return out
+
+
 # ---- scalar helpers of the reference (pure integer logic, no points) ------------------
 def order(curve) -> int:                                   # src/argument_witness_calc.rs:54-56
     return ORDER[_curve_id(curve)]

@@ -717,6 +717,14 @@ void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W window sums */, 
   G::to_jacobian(acc, out);
 }
 
+template <class P64>
+void jacobian_sum_t(const uint64_t* jac, size_t count, uint64_t out[12]) {
+  typedef host::HG<P64> G;
+  host::pt acc = G::identity();
+  for (size_t i = 0; i < count; i++) acc = G::add(acc, G::from_jacobian(jac + 12 * i));
+  G::to_jacobian(acc, out);
+}
+
 template <class P64, class G>
 int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, u32 wb, u32 we,
                   std::vector<host::pt>& out) {
@@ -1257,6 +1265,14 @@ int lemsm_jacobian_to_canonical(int curve, const uint64_t jac[12], uint8_t out[6
     x = F::mul(x, one_plain); y = F::mul(y, one_plain);
     memcpy(out, x.l, 32); memcpy(out + 32, y.l, 32);
   }
+  return LEMSM_OK;
+}
+
+int lemsm_jacobian_sum(int curve, const uint64_t* jac, size_t count, uint64_t out[12]) {
+  if (!out || (count && !jac)) return LEMSM_ERR_BAD_ARG;
+  if (curve == LEMSM_BN254_G1) jacobian_sum_t<host::FqParams64>(jac, count, out);
+  else if (curve == LEMSM_GRUMPKIN) jacobian_sum_t<host::FrParams64>(jac, count, out);
+  else return LEMSM_ERR_BAD_CURVE;
   return LEMSM_OK;
 }
 

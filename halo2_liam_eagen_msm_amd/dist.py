@@ -70,3 +70,40 @@ def sharded_lhs_msm(ctx, curve, d_scalars: int, d_points_affine: int, n: int, ba
     local = ctx.lhs_partial_device(curve, d_scalars, d_points_affine, n, base, p0, p1)
     allrec = all_gather_records(local, d, rec, world, rank, device, group)
     return ctx.lhs_combine(curve, base, allrec)
+
+
+def point_range(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous balanced split of the pairs: rank r owns [n*r//G, n*(r+1)//G)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def sharded_msm_by_points(ctx, curve, d_scalars: int, d_points: int, n: int, world: int, rank: int, device=None,
+                          group=None) -> np.ndarray:
+    """The alternative partition: rank r runs the whole pipeline (all windows) over
+    its own n/G pairs -- `d_scalars` / `d_points` address the FULL arrays here, a rank with only its
+    slice resident passes slice pointers and (n, world=1 ranges) itself -- and the ranks all-gather
+    one 96-byte Jacobian partial each, which every rank sums on the host.  This is the structure of
+    halo2's best_multiexp itself (chunks of pairs per thread, partial results folded).  Nothing is
+    replicated (the digit pass and the point conversion shard too), so a rank's device time at
+    8 GPUs is ~10 % lower than with window sharding (profiles/r01/o_shard_rehearsal_one_gpu.txt);
+    window sharding stays the default because the north star prescribes it."""
+    a, b = point_range(n, world, rank)
+    local = ctx.msm_device(curve, d_scalars + a * 32, d_points + a * 64, b - a) if b > a else np.zeros(12, np.uint64)
+    from .api import jacobian_sum
+    if world == 1:
+        return local
+    allj = all_gather_fixed(np.ascontiguousarray(local, np.uint64).view(np.uint8), world, device, group)
+    return jacobian_sum(curve, allj.view(np.uint64).reshape(world, 12))
+
+
+def all_gather_fixed(local_bytes: np.ndarray, world: int, device=None, group=None) -> np.ndarray:
+    """All-gather of one fixed-size byte record per rank; returns (world, len) uint8."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(np.ascontiguousarray(local_bytes, np.uint8).reshape(-1).copy())
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.cpu().numpy().reshape(world, -1)

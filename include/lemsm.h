@@ -159,6 +159,11 @@ int lemsm_precompute_multiplicities_affine(lemsm_ctx* ctx, int curve, const uint
 /* Jacobian -> canonical comparison form: affine x||y, 32-byte little-endian canonical
    (non-Montgomery) integers; identity = 64 zero bytes. */
 int lemsm_jacobian_to_canonical(int curve, const uint64_t jacobian[12], uint8_t out[64]);
+/* Sum of `count` Jacobian points on the host (identity for count == 0).  Combines the partial
+   results of an MSM whose POINTS were split across callers / GPUs -- the step halo2's
+   best_multiexp performs over its per-thread chunk results (`results.iter().fold(identity, a + b)`
+   in the halo2_proofs dependency the reference calls at src/argument_witness_calc.rs:223). */
+int lemsm_jacobian_sum(int curve, const uint64_t* jacobian, size_t count, uint64_t out[12]);
 /* Device memory helpers so that non-HIP hosts can stage resident inputs. */
 int lemsm_device_alloc(lemsm_ctx* ctx, size_t bytes, void** out);
 int lemsm_device_free(lemsm_ctx* ctx, void* p);

@@ -36,6 +36,18 @@ def _worker(rank, world, port, kind, q):
             allrec = ldist.all_gather_records(local, W, rec, world, rank)
             out = hostref.msm_combine(curve, n, allrec.tobytes())
             ok = cref.jac_to_canonical(curve.cid, out) == curve.canonical(curve.msm_naive(sc, pts))
+        elif kind == "points":
+            # the alternative partition: pairs split across ranks, one Jacobian partial per rank
+            # (oracle-built, arbitrary Z), ONE all-gather, product-library host sum on every rank
+            from halo2_liam_eagen_msm_amd import api
+            sc = pyref.gen_scalars_full(rng, n, curve.order)
+            a, b = ldist.point_range(n, world, rank)
+            part = curve.msm_naive(sc[a:b], pts[a:b])
+            z = 1 + pyref.SplitMix64(77 + rank).next256() % (curve.fp - 1)
+            local = np.frombuffer(curve.affine_to_jacobian_raw(part, z), np.uint8)
+            allj = ldist.all_gather_fixed(local, world)
+            out = api.jacobian_sum(curve.cid, allj.view(np.uint64).reshape(world, 12))
+            ok = cref.jac_to_canonical(curve.cid, out) == curve.canonical(curve.msm_naive(sc, pts))
         else:
             sc = pyref.gen_scalars_half(rng, n, curve.order)
             d, rec, recs = hostref.lhs_records(curve, sc, pts, 16)
@@ -52,7 +64,7 @@ def _worker(rank, world, port, kind, q):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("kind", ["msm", "lhs"])
+@pytest.mark.parametrize("kind", ["msm", "lhs", "points"])
 def test_window_sharded_combine_gloo(world, kind):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -77,3 +89,12 @@ def test_window_range_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_point_range_partition():
+    from halo2_liam_eagen_msm_amd.dist import point_range
+    for n in (0, 1, 7, 1 << 20, (1 << 24) + 5):
+        for G in (1, 2, 3, 8):
+            spans = [point_range(n, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))

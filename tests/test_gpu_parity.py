@@ -320,6 +320,24 @@ def test_msm_length_mismatch(ctx):
         ctx.msm(0, sc, pts)
 
 
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_msm_point_partials_sum(ctx, parts):
+    """the alternative multi-GPU partition (pairs split across ranks): the ranks'
+    Jacobian partials, summed by lemsm_jacobian_sum, are the same group element as the whole MSM"""
+    from halo2_liam_eagen_msm_amd import dist as ldist
+    curve = pyref.BN254_G1
+    n = 5003
+    pts = cref.gen_points(curve.cid, 61, n); sc = cref.gen_scalars(curve.cid, 62, n)
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    partials = []
+    for r in range(parts):
+        a, b = ldist.point_range(n, parts, r)
+        partials.append(ctx.msm_device(curve.cid, ds.ptr + a * 32, dp.ptr + a * 64, b - a))
+    got = api.jacobian_sum(curve.cid, np.stack(partials))
+    assert canon(curve, got) == canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    assert canon(curve, got) == canon(curve, ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n))
+
+
 # ------------------------------------------------------------------ window sharding
 @pytest.mark.parametrize("parts", [1, 2, 3, 8])
 def test_msm_window_partials_combine(ctx, parts):

@@ -96,3 +96,29 @@ def test_product_fails_loudly_without_gpu():
         assert rc == _lib.LEMSM_ERR_HIP
         with pytest.raises(api.LemsmError):
             api.Context(0)
+
+
+def test_jacobian_sum_host():
+    """lemsm_jacobian_sum: host-side fold of partial results (no GPU): identity handling,
+    P + (-P), doubling (equal inputs), random sums vs the big-int oracle"""
+    import numpy as np
+    from halo2_liam_eagen_msm_amd import api
+    from oracle import cref, pyref
+    for curve in (pyref.BN254_G1, pyref.GRUMPKIN):
+        rng = pyref.SplitMix64(991 + curve.cid)
+        pts = pyref.gen_points(curve, rng, 6)
+        def jac(pt):
+            z = 1 + rng.next256() % (curve.fp - 1)
+            return np.frombuffer(curve.affine_to_jacobian_raw(pt, z), np.uint64)
+        ident = np.zeros(12, np.uint64)
+        assert cref.jac_to_canonical(curve.cid, api.jacobian_sum(curve.cid, np.zeros((0, 12), np.uint64))) == bytes(64)
+        assert cref.jac_to_canonical(curve.cid, api.jacobian_sum(curve.cid, np.stack([ident, ident]))) == bytes(64)
+        neg = (pts[0][0], (-pts[0][1]) % curve.fp)
+        assert cref.jac_to_canonical(curve.cid, api.jacobian_sum(curve.cid, np.stack([jac(pts[0]), jac(neg)]))) == bytes(64)
+        got = api.jacobian_sum(curve.cid, np.stack([jac(pts[1]), ident, jac(pts[1])]))
+        assert cref.jac_to_canonical(curve.cid, got) == curve.canonical(curve.add(pts[1], pts[1]))
+        acc = None
+        for p_ in pts:
+            acc = curve.add(acc, p_)
+        got = api.jacobian_sum(curve.cid, np.stack([jac(p_) for p_ in pts]))
+        assert cref.jac_to_canonical(curve.cid, got) == curve.canonical(acc)
