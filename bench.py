@@ -130,6 +130,10 @@ def main():
     d_points = ctx.gen_walk(cid, q, n)
     t_in = time.time() - t_in
 
+    if world > 1 and args.workload == "msm" and args.sharding == "windows":
+        # 16 windows split evenly over 2/4/8 ranks; the single-GPU default at 2^24 (15 windows of 17 bits) does not
+        ctx.set_option("window_bits", 16)
+
     def step():
         if args.workload == "msm":
             if world == 1:

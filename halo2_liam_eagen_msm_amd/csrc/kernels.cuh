@@ -237,10 +237,11 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
                                                   u32* __restrict__ meta) {
   __shared__ u32 wsum[16];
   const u32 t = threadIdx.x;
-  u32 cnt[4], tl[4], s = 0, st = 0;
+  constexpr int PB = MAX_BINS / 1024;   // bins per thread
+  u32 cnt[PB], tl[PB], s = 0, st = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    u32 b = t * 4 + k;
+  for (int k = 0; k < PB; k++) {
+    u32 b = t * PB + k;
     cnt[k] = b < pl.nbins ? bin_total[b] : 0;
     tl[k] = (cnt[k] + pl.T2 - 1) / pl.T2;
     s += cnt[k]; st += tl[k];
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
   u32 off = block_excl_scan_1024(s, &tot, wsum);
   u32 offt = block_excl_scan_1024(st, &tott, wsum);
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    u32 b = t * 4 + k;
+  for (int k = 0; k < PB; k++) {
+    u32 b = t * PB + k;
     if (b < pl.nbins) { bin_start[b] = off; tile_prefix[b] = offt; }
     off += cnt[k]; offt += tl[k];
   }

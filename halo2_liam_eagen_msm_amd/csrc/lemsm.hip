@@ -150,18 +150,33 @@ struct MsmPlan {
 u32 choose_c(const lemsm_ctx* ctx, size_t n) {
   if (ctx && ctx->opt_window_bits >= 2 && ctx->opt_window_bits <= 17) return (u32)ctx->opt_window_bits;
   u32 lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
-  // (17-bit windows are supported through the option -- 15 windows of 2^16 buckets, 4 % less
-  // accumulation time at 2^24 -- but measured no faster end to end: two window groups double the
-  // latency-bound tail and the digit pass; profiles/r01/ab_c16_vs_c17.txt)
+  // 17-bit windows (15 windows of 2^16 buckets, 512 coarse bins each, one window group) from 2^24
+  // points per slab: 6 % less accumulation, 0.5 ms more sort + tail -> 3 % faster end to end at
+  // 2^24, a wash below (profiles/r01/p_c16_vs_c17_one_group.txt).  Window-sharded multi-GPU runs
+  // pin 16 (dist.py): 16 windows split evenly over 2/4/8 ranks, 15 do not.
+  if (lg >= 24) return 17;
   int c = (int)lg - 3;
   if (c < 3) c = 3;
   if (c > 16) c = 16;
   return (u32)c;
 }
 
+// host-pointer entries: log2 of the slab of pairs uploaded while the previous slab is accumulated.
+// auto: a quarter of the input, between 2^19 (below that the fixed ~0.5 ms tail of a slab costs more
+// than the overlap hides) and 2^21 (measured best at 2^24: profiles/r01/n_host_pointer_slab_pipeline.txt)
+u32 host_slab_log(const lemsm_ctx* ctx, size_t n) {
+  u32 lg = 0; while (((size_t)2 << lg) <= n) lg++;   // floor(log2 n)
+  u32 auto_log = std::min(21u, std::max(19u, lg >= 2 ? lg - 2 : 0u));
+  return std::min<u32>(MAX_SLAB_LOG, ctx->opt_host_slab_bits ? (u32)ctx->opt_host_slab_bits : auto_log);
+}
+
 MsmPlan make_msm_plan(const lemsm_ctx* ctx, int curve, size_t n) {
   MsmPlan p; memset(&p, 0, sizeof p);
-  p.c = choose_c(ctx, n);
+  // the window width follows the number of pairs one pass of the pipeline sees (a slab), not the call's total
+  size_t n_pass = n;
+  if (ctx && ctx->host_stage) n_pass = std::min(n, (size_t)1 << host_slab_log(ctx, n));
+  else if (ctx && ctx->opt_slab_bits) n_pass = std::min(n, (size_t)1 << ctx->opt_slab_bits);
+  p.c = choose_c(ctx, n_pass);
   p.nb = 1u << (p.c - 1);
   p.nbp = p.nb; p.L = ilog2(p.nbp);
   const u32* order = order_of(curve);
@@ -582,13 +597,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   // k+1 (upload queue, host blocked in the copy) overlaps the kernels of slab k (main queue).
   const HostStage* hs = ctx->host_stage;
   u32 slab_log = ctx->opt_slab_bits ? (u32)ctx->opt_slab_bits : MAX_SLAB_LOG;
-  if (hs) {
-    // auto: a quarter of the input per slab, between 2^19 (below that the fixed ~0.5 ms tail of a
-    // slab costs more than the overlap hides) and 2^21 (measured best at 2^24: profiles/r01/host_pointer_*)
-    u32 lg = 0; while (((size_t)2 << lg) <= n) lg++;   // floor(log2 n)
-    u32 auto_log = std::min(21u, std::max(19u, lg >= 2 ? lg - 2 : 0u));
-    slab_log = std::min<u32>(MAX_SLAB_LOG, ctx->opt_host_slab_bits ? (u32)ctx->opt_host_slab_bits : auto_log);
-  }
+  if (hs) slab_log = host_slab_log(ctx, n);
   const size_t SLAB = (size_t)1 << slab_log;
   const size_t nslabs = (n + SLAB - 1) / SLAB;
   u32 gmax = max_group_windows(nb);

@@ -5,7 +5,7 @@
 namespace lemsm {
 
 // Maximum coarse bins per pass-1 launch (LDS histogram: 2 x 4096 x 4 B = 32 KiB).
-static const uint32_t MAX_BINS = 4096;
+static const uint32_t MAX_BINS = 8192;
 // Local (within-bin) bucket bits carried in a pass-1 entry.
 static const uint32_t MAX_LB = 7;
 // Points per slab: a pass-1 entry packs idx(24) | local(7) | sign(1).

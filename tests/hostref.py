@@ -14,9 +14,9 @@ def msm_plan(curve, n):
     w = ctypes.c_uint32(); b = ctypes.c_size_t()
     assert lib.lemsm_msm_plan(None, curve.cid, n, ctypes.byref(w), ctypes.byref(b)) == 0
     assert b.value == 128
-    # window bits c: the library's rule (choose_c in csrc/lemsm.hip): clamp(floor(log2 n) - 3, 3, 16)
+    # window bits c: the library's rule (choose_c in csrc/lemsm.hip): clamp(floor(log2 n) - 3, 3, 16) below 2^24 pairs
     lg = n.bit_length() - 1
-    c = max(3, min(16, lg - 3))
+    c = 17 if lg >= 24 else max(3, min(16, lg - 3))
     return w.value, c - 1, b.value   # windows, L (c = L + 1), record bytes
 
 

@@ -517,7 +517,8 @@ def test_lhs_large_walk_relation(ctx):
 
 
 # ------------------------------------------------------------------ larger sizes: properties
-@pytest.mark.parametrize("curve,logn", [(pyref.BN254_G1, 16), (pyref.GRUMPKIN, 16), (pyref.BN254_G1, 20), (pyref.GRUMPKIN, 22)], ids=["bn254-2^16", "grumpkin-2^16", "bn254-2^20", "grumpkin-2^22"])
+@pytest.mark.parametrize("curve,logn", [(pyref.BN254_G1, 16), (pyref.GRUMPKIN, 16), (pyref.BN254_G1, 20), (pyref.GRUMPKIN, 22), (pyref.BN254_G1, 24)],
+                         ids=["bn254-2^16", "grumpkin-2^16", "bn254-2^20", "grumpkin-2^22", "bn254-2^24-bench-size-17-bit-windows"])
 def test_msm_walk_relation_large(ctx, curve, logn):
     """P_i = (i+1) Q  =>  sum s_i P_i == (sum s_i (i+1)) Q, checked with one scalar multiplication;
     the device-generated points are spot-checked against the oracle."""

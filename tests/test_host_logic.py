@@ -35,7 +35,8 @@ def test_msm_plan_windows():
             K = sum((1 << (cbits - 1)) << (cbits * w) for w in range(W - 1))
             assert ((c.order - 1 + K) >> (cbits * (W - 1))) <= (1 << (cbits - 1))   # top window fits the buckets
             assert (c.order - 1 + K) >> (cbits * W) == 0
-        assert hostref.msm_plan(c, 1 << 24)[0] == 16    # 16-bit windows: 16 windows, 8/4/2 per rank on 2/4/8 GPUs
+        assert hostref.msm_plan(c, 1 << 23)[0] == 16    # 16-bit windows: 16 windows, 8/4/2 per rank on 2/4/8 GPUs
+        assert hostref.msm_plan(c, 1 << 24)[0] == 15    # 17-bit windows from 2^24 pairs (single-GPU default)
 
 
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
