@@ -37,8 +37,9 @@ struct KAdd { u32 k[8]; u32 order[8]; };   // window offset constant K and the s
 // Signed-window Pippenger: s' = s + K with K = sum_{w<W-1} 2^(c-1) 2^(cw).  The raw c-bit windows
 // of s' are written window-major (dig16[(w-w0)*n + j], one coalesced 2-byte column per window) so
 // that the sort passes stream one window at a time.
-template <int MODE /* 0: any c <= 16, 1: c == 16, 2: c == 17 (sign bitmap beside the u16 column) */>
-__global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ scalars, KAdd kadd, GroupPlan pl,
+template <int MODE /* 0: any c <= 16, 1: c == 16, 2: c == 17 (sign bitmap beside the u16 column) */,
+          int BS = 256 /* threads per block: 1024 when there are too few ranges to fill the chip with 256 */>
+__global__ __launch_bounds__(BS) void k_pip_digits(const uint4* __restrict__ scalars, KAdd kadd, GroupPlan pl,
                                                     uint16_t* __restrict__ dig16, unsigned long long* __restrict__ signbm,
                                                     u32* __restrict__ block_counts,
                                                     u32* __restrict__ bin_total, u32* __restrict__ err) {
@@ -46,21 +47,21 @@ __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ sc
   // columns AND the per-(window, range, bin) counts the scatter needs (no separate count pass)
   __shared__ u32 hist[MAX_BINS];
   const u32 tid = threadIdx.x, r = blockIdx.x;
-  for (u32 i = tid; i < pl.nbins; i += 256) hist[i] = 0;
+  for (u32 i = tid; i < pl.nbins; i += BS) hist[i] = 0;
   __syncthreads();
   const u32 half = 1u << (pl.c - 1);
   u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
-  for (u32 jb = j0 + tid; jb < j1; jb += 256 * 4) {
+  for (u32 jb = j0 + tid; jb < j1; jb += BS * 4) {
     uint4 a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {     // four scalars in flight per thread
-      u32 j = jb + 256u * u;
+      u32 j = jb + (u32)BS * u;
       if (j < j1) { a[u] = scalars[2 * (size_t)j]; b[u] = scalars[2 * (size_t)j + 1]; }
       else { a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u]; }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      u32 j = jb + 256u * u;
+      u32 j = jb + (u32)BS * u;
       if (j >= j1) continue;   // wave-uniform for MODE 2's ballot: ranges and n are handled in whole waves (see below)
       u32 s[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
       // scalars must be canonical (< order), as PrimeField::to_repr() guarantees; anything else is
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pip_digits(const uint4* __restrict__ sc
     }
   }
   __syncthreads();
-  for (u32 i = tid; i < pl.nbins; i += 256) {
+  for (u32 i = tid; i < pl.nbins; i += BS) {
     u32 cnt = hist[i];
     u32 wl = i / pl.BW, bin = i - wl * pl.BW;
     block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + bin] = cnt;
@@ -365,20 +366,26 @@ __global__ __launch_bounds__(256) void k_count2(GroupPlan pl, const u32* __restr
   }
 }
 
-// bucket_start[(nbins << LB) + 1]: one thread per bin
+// bucket_start[(nbins << LB) + 1]: one thread per bucket, one block = 256 >> LB whole bins.
+// (A thread per bin walking its 2^LB counts serially was a 50 us latency chain with strided loads.)
 __global__ __launch_bounds__(256) void k_bucketscan(GroupPlan pl, const u32* __restrict__ bin_start,
                                                     const u32* __restrict__ bucket_count,
                                                     u32* __restrict__ bucket_start) {
-  u32 b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= pl.nbins) return;
-  u32 run = bin_start[b];
-  u32 nl = 1u << pl.LB;
-  for (u32 l = 0; l < nl; l++) {
-    u32 key = (b << pl.LB) + l;
-    bucket_start[key] = run;
-    run += bucket_count[key];
+  __shared__ u32 ex[256];
+  __shared__ u32 wsum[4];
+  const u32 tid = threadIdx.x;
+  const u32 key = blockIdx.x * 256 + tid;
+  const u32 nkeys = pl.nbins << pl.LB;
+  u32 cnt = key < nkeys ? bucket_count[key] : 0u;
+  u32 total;
+  u32 e = block_excl_scan_256(cnt, &total, wsum);
+  ex[tid] = e;
+  __syncthreads();
+  if (key < nkeys) {
+    u32 first = tid & ~((1u << pl.LB) - 1u);          // first bucket of this thread's bin inside the block
+    bucket_start[key] = bin_start[key >> pl.LB] + (e - ex[first]);
   }
-  if (b == pl.nbins - 1) bucket_start[pl.nbins << pl.LB] = run;
+  if (key == 0) bucket_start[nkeys] = bin_start[pl.nbins];
 }
 
 __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __restrict__ entries,

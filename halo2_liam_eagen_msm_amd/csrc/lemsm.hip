@@ -83,7 +83,7 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0;
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   size_t bad_index = 0;
@@ -312,7 +312,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
   size_t o_entries = take(Mmax * 4 + 16), o_sorted = take(Mmax * 4 + 16);
   size_t R1 = 2 * (size_t)pl.nthr1;
-  size_t R2 = 2 * ((R1 + L2_RECORDS - 1) / L2_RECORDS);
+  size_t R2 = 2 * ((R1 + 1) / 2);   // first edge level writes 2 records per `per` >= 2 inputs (option seg_records)
   size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * ptb + 256), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * ptb + 256);
   w.total = off;
   if (base) {
@@ -353,8 +353,10 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   u32 L1;
   if (ctx->opt_chunk > 0) L1 = (u32)ctx->opt_chunk;
   else {
-    size_t target = (size_t)256 * 4 * 4 * 64;
-    size_t l = Mmax / target;
+    // two full rounds of the accumulate kernel's 3 waves per SIMD (256 CUs x 4 SIMDs x 3 x 64 lanes x 2):
+    // measured best at 2^20..2^22 (profiles/r01/q_chunk_sweep.txt); from 2^23 the cap of 256 applies
+    size_t target = (size_t)256 * 4 * 3 * 64 * 2;
+    size_t l = (Mmax + target - 1) / target;
     L1 = (u32)std::max((size_t)8, std::min((size_t)256, l));
   }
   g.L1 = L1;
@@ -383,10 +385,17 @@ struct PipProvider {
     if (pl.c == 17) {
       dec.signbm = signbm;
       hipLaunchKernelGGL((k_pip_digits<2>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
-    } else if (pl.c == 16 && pl.W == 16)
-      hipLaunchKernelGGL((k_pip_digits<1>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
-    else
-      hipLaunchKernelGGL((k_pip_digits<0>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+    } else if (pl.c == 16 && pl.W == 16) {
+      if (pl.nblk1 < 1024)   // too few ranges to fill 256 CUs with 256-thread blocks
+        hipLaunchKernelGGL((k_pip_digits<1, 1024>), dim3(pl.nblk1), dim3(1024), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+      else
+        hipLaunchKernelGGL((k_pip_digits<1>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+    } else {
+      if (pl.nblk1 < 1024)
+        hipLaunchKernelGGL((k_pip_digits<0, 1024>), dim3(pl.nblk1), dim3(1024), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+      else
+        hipLaunchKernelGGL((k_pip_digits<0>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+    }
     return LEMSM_OK;
   }
 };
@@ -448,7 +457,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   if (pl.LB > 0) {
     hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
     hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
-    hipLaunchKernelGGL(k_bucketscan, dim3((pl.nbins + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
+    hipLaunchKernelGGL(k_bucketscan, dim3(((pl.nbins << pl.LB) + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
     hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info,
                        w.bucket_start, w.bucket_cursor, w.sorted);
     d_sorted = w.sorted; d_bstart = w.bucket_start;
@@ -482,8 +491,9 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     // first level: 8 records per thread, serial (work-efficient while most records are real);
     // later levels: one record per lane with a wavefront segmented scan (6 additions deep, 32x shrink)
     {
-      u32 nthr = (R + L2_RECORDS - 1) / L2_RECORDS;
-      hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, L2_RECORDS, ik, ip,
+      u32 per = ctx->opt_seg_records ? (u32)ctx->opt_seg_records : L2_RECORDS;
+      u32 nthr = (R + per - 1) / per;
+      hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, per, ik, ip,
                          w.arena + (size_t)ar.bucket_off * ptb, ok, op);
       R = 2 * nthr;
       std::swap(ik, ok); std::swap(ip, op);
@@ -1023,6 +1033,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
+  else if (!strcmp(name, "seg_records")) { if (value < 0 || value > 64 || value == 1) return LEMSM_ERR_BAD_ARG; ctx->opt_seg_records = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
   else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }

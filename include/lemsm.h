@@ -80,7 +80,8 @@ size_t lemsm_last_bad_index(const lemsm_ctx* ctx);
    pipelined over three queues, device-pointer entries only; 0 = one group),
    "host_slab_bits" (host-pointer entries: log2 of the slab of pairs uploaded while the previous
    slab is being accumulated; 0 = auto = 21), "slab_bits" (device-pointer entries: log2 of the
-   slab of pairs one pass of the pipeline covers; 0 = auto = 24, smaller values are a test knob). */
+   slab of pairs one pass of the pipeline covers; 0 = auto = 24, smaller values are a test knob),
+   "seg_records" (edge records per thread at the first reduction level, 0 = auto = 8). */
 int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value);
 /* Device-time (ms, from HIP events on the context's stream) of the last MSM call: whole
    pipeline in [0], the dominant accumulate kernel in [1], its launch count in [2]. */
