@@ -11,8 +11,10 @@
 // side accumulators (extra 64-bit adds, spills), and it pads every asm statement with an s_nop.
 //
 // Domain: kernels using this field work on x * 2^261 mod N.  The C ABI's raw-Montgomery
-// format is x * 2^256 (8 x u32): k_convert_points multiplies by 2^5 once per point per MSM,
-// and the host multiplies the few hundred result coordinates by 2^-5 (hostmath.hpp).
+// format is x * 2^256 (8 x u32).  Either k_convert_points multiplies every point by 2^5 once per
+// MSM, or (long buckets / few windows per call) the accumulate kernel consumes the ABI form directly
+// by carrying ZZ and ZZZ times 2^5 (XYZZ29::madd_abi).  The host multiplies the few hundred result
+// coordinates by 2^-5 (hostmath.hpp).
 //
 // Invariants ("N" = normalised): limbs 0..7 in [0, 2^29), limb 8 a small signed value; the
 // integer value V (any representative of the residue) satisfies |V| < 8N.  Every mont*() output
@@ -35,12 +37,14 @@ struct Fq29Params {   // BN254 base field p
   static constexpr u32 NINV = 0x04866389u;   // -N^-1 mod 2^29
   static constexpr i32 ONE[9] = {0x157ccc21, 0x141c2758, 0x185230d3, 0x014c0419, 0x0aa36fb9, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836};    // 2^261 mod N
   static constexpr i32 C266[9] = {0x13349ca1, 0x1a5d84a8, 0x0a3e5cac, 0x100249e0, 0x12b951e8, 0x0e92d304, 0x14cb95b3, 0x041b9d3d, 0x00058003};   // 2^266 mod N
+  static constexpr i32 C256[9] = {0x058f0d9d, 0x1aea1c6e, 0x11c2cf74, 0x11d651eb, 0x1462c0a7, 0x11b7bc3c, 0x1cbd99ba, 0x183340fb, 0x000e0a77};   // 2^256 mod N
 };
 struct Fr29Params {   // BN254 scalar field r
   static constexpr i32 N[9] = {0x10000001, 0x1f0fac9f, 0x0e5c2450, 0x07d090f3, 0x1585d283, 0x02db40c0, 0x00a6e141, 0x0e5c2634, 0x0030644e};
   static constexpr u32 NINV = 0x0fffffffu;
   static constexpr i32 ONE[9] = {0x0fffff57, 0x1ea70ab4, 0x052c068b, 0x17504f49, 0x0aa8075b, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836};
   static constexpr i32 C266[9] = {0x0fffead7, 0x1d5444f4, 0x04438aa5, 0x03b4d096, 0x134c84da, 0x0e92d304, 0x14cb95b3, 0x041b9d3d, 0x00058003};
+  static constexpr i32 C256[9] = {0x0ffffffb, 0x04b1a0e2, 0x18334a6b, 0x18ed2b3e, 0x1462e36f, 0x11b7bc3c, 0x1cbd99ba, 0x183340fb, 0x000e0a77};
 };
 
 template <class P>
@@ -167,12 +171,38 @@ struct Field29 {
     q[0] = make_uint4(w[0], w[1], w[2], w[3]);
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
   }
-  // x*2^256 (ABI raw Montgomery, canonical) -> x*2^261
+  // x*2^256 (ABI raw Montgomery) -> x*2^261; equally: times 32 inside the 2^261 domain
   static __device__ __forceinline__ void from_abi(fe& r, const fe& a) {
     fe c;
 #pragma unroll
     for (int i = 0; i < 9; i++) c.l[i] = P::C266[i];
     mul(r, a, c);
+  }
+  // divide by 32 inside the 2^261 domain (multiply by the domain image of 2^-5, which is 2^256)
+  static __device__ __forceinline__ void div32(fe& r, const fe& a) {
+    fe c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.l[i] = P::C256[i];
+    mul(r, a, c);
+  }
+  // r = 32 * a as a lazy value, WITHOUT a Montgomery multiplication: 32a - q N with q estimated
+  // from the top limbs, so r is congruent to 32a with |r| < 4N, limbs normalised (~50 instructions
+  // instead of ~225).  a: canonical limbs, possibly negated as a whole (|limb| < 2^29).
+  // Since 32 = 2^261 / 2^256 this also takes x*2^256 (the C ABI's form) to x*2^261.
+  static __device__ __forceinline__ void mul32(fe& r, const fe& a) {
+    const float inv = 32.0f / (float)P::N[8];
+    i32 q = (i32)((float)a.l[8] * inv);            // |32a/N - q| < 2
+    i64 t = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      t += (i64)a.l[i] * 32 - (i64)q * P::N[i];
+      if (i < 8) { r.l[i] = (i32)t & MASK; t >>= 29; }
+      else r.l[i] = (i32)t;
+    }
+  }
+  static __device__ __forceinline__ void set_c266(fe& r) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = P::C266[i];
   }
 };
 

@@ -19,7 +19,8 @@ enum { META_M = 0, META_TILES = 1, META_WORDS = 4 };
 // chunk) that covers its whole bucket is stored to bucket_sum[key]; otherwise it becomes an
 // edge record (at most two per thread: first and last segment) for the next level.
 // ------------------------------------------------------------------------------------
-template <class G, int WPS /* waves per SIMD the register budget is sized for */>
+template <class G, int WPS /* waves per SIMD the register budget is sized for */,
+          bool ABI = false /* points in the C ABI's domain, accumulator and outputs in the scaled form: G::madd_abi */>
 __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __restrict__ sorted,
                                                 const u32* __restrict__ bucket_start, const u32* __restrict__ meta,
                                                 const uint4* __restrict__ points, char* __restrict__ bucket_sum,
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
     }
     if (!G::aff_is_identity(px, py)) {
       F::cneg(py, py, (e >> 31) != 0);
-      G::madd(acc, px, py);
+      if (ABI) G::madd_abi(acc, px, py); else G::madd(acc, px, py);
     }
   }
   flush(end);
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
 // decided from the neighbouring record keys.  R = number of input records.
 // ------------------------------------------------------------------------------------
 template <class G>
-__global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, const u32* __restrict__ in_key,
+__global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, u32 scaled /* k_accum1 ran in its ABI form */,
+                                                   const u32* __restrict__ in_key,
                                                    const char* __restrict__ in_pt, char* __restrict__ bucket_sum,
                                                    u32* __restrict__ out_key, char* __restrict__ out_pt) {
   const u32 t = blockIdx.x * 256 + threadIdx.x;
@@ -123,7 +125,9 @@ __global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, const u32* __re
   auto flush = [&](bool touches_end) {
     bool complete = !(open_from_start && prev_key == cur) && !(touches_end && next_key == cur);
     if (complete) {
-      G::store(bucket_sum + (size_t)cur * G::PT_BYTES, acc);
+      typename G::pt sc = acc;
+      if (scaled) G::scale(sc);                     // bucket_sum[] then holds the scaled form (xyzz29.cuh)
+      G::store(bucket_sum + (size_t)cur * G::PT_BYTES, sc);
     } else {
       u32 slot = r0 + nrec;
       out_key[slot] = cur;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, const u32* __re
       G::set_identity(acc);
     }
     typename G::pt q; G::load(q, in_pt + (size_t)i * G::PT_BYTES);
+    if (scaled) G::unscale(q);                     // k_accum1's records are (X, Y, 32 ZZ, 32 ZZZ); ours are plain
     G::add(acc, q);
   }
   if (cur != KEY_NONE) flush(true);
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, const u32* __re
 // the same filler rule as above.
 // ------------------------------------------------------------------------------------
 template <class G>
-__global__ __launch_bounds__(256) void k_segwave(u32 R, const u32* __restrict__ in_key, const char* __restrict__ in_pt,
+__global__ __launch_bounds__(256) void k_segwave(u32 R, u32 scaled, const u32* __restrict__ in_key, const char* __restrict__ in_pt,
                                                  char* __restrict__ bucket_sum, u32* __restrict__ out_key,
                                                  char* __restrict__ out_pt) {
   const u32 gid = blockIdx.x * 256 + threadIdx.x;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void k_segwave(u32 R, const u32* __restrict__ 
   const bool before = from_lane0 && prev_glob == key && key != KEY_NONE;
   const bool holder = last_of_run || open_end;                       // lane holding its run's in-wave sum
   const bool edge = holder && (before || open_end);
-  if (holder && !edge) G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc);
+  if (holder && !edge) { typename G::pt sc = acc; if (scaled) G::scale(sc); G::store(bucket_sum + (size_t)key * G::PT_BYTES, sc); }
   unsigned long long em = __ballot(edge);
   const u32 nedge = __popcll(em);
   const u32 o0 = 2 * wave;
@@ -222,6 +227,7 @@ struct PyrTask {
   u32 src_off, src_wstride;   // per-window base = src_off + w * src_wstride
   u32 dst_off, dst_wstride;
   u32 stride, phase, count, src_valid;
+  u32 src_scaled, pad_[3];    // source is bucket_sum[] in the scaled form: convert on load
 };
 
 template <class G>
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tas
   typename G::pt a, b;
   if (ia < tk.src_valid) G::load(a, src + (size_t)ia * G::PT_BYTES); else G::set_identity(a);
   if (ib < tk.src_valid) G::load(b, src + (size_t)ib * G::PT_BYTES); else G::set_identity(b);
+  if (tk.src_scaled) { G::unscale(a); G::unscale(b); }
   G::add(a, b);
   G::store(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride + i) * G::PT_BYTES, a);
 }

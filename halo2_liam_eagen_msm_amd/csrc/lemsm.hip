@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <string>
 #include <vector>
@@ -39,8 +40,8 @@ const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUN
 }  // namespace
 // heavy kernels are instantiated in inst_*.hip
 #define LEMSM_EXTERN_G(G)                                                                                   \
-  extern template __global__ void lemsm::k_segreduce<G>(u32, u32, const u32*, const char*, char*, u32*, char*); \
-  extern template __global__ void lemsm::k_segwave<G>(u32, const u32*, const char*, char*, u32*, char*);                     \
+  extern template __global__ void lemsm::k_segreduce<G>(u32, u32, u32, const u32*, const char*, char*, u32*, char*); \
+  extern template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);                     \
   extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
 #define LEMSM_EXTERN_ACC(G, W) \
   extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
@@ -48,6 +49,8 @@ LEMSM_EXTERN_G(GqStrict) LEMSM_EXTERN_G(GrStrict) LEMSM_EXTERN_G(GqLazy) LEMSM_E
 LEMSM_EXTERN_ACC(GqStrict, 4) LEMSM_EXTERN_ACC(GrStrict, 4)
 LEMSM_EXTERN_ACC(GqLazy, 2) LEMSM_EXTERN_ACC(GqLazy, 3) LEMSM_EXTERN_ACC(GqLazy, 4)
 LEMSM_EXTERN_ACC(GrLazy, 2) LEMSM_EXTERN_ACC(GrLazy, 3) LEMSM_EXTERN_ACC(GrLazy, 4)
+extern template __global__ void lemsm::k_accum1<GqLazy, 3, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+extern template __global__ void lemsm::k_accum1<GrLazy, 3, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
 extern template __global__ void lemsm::k_convert_points<Field29<Fq29Params>>(const uint4*, uint4*, u32);
 extern template __global__ void lemsm::k_convert_points<Field29<Fr29Params>>(const uint4*, uint4*, u32);
 namespace {
@@ -83,7 +86,7 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0;
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   size_t bad_index = 0;
@@ -231,12 +234,12 @@ ArenaLayout make_arena(u32 NBpad, u32 nbp, u32 gw, u32 L) {
   return a;
 }
 
-PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbw, u32 nbp, u32 L) {
+PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbw, u32 nbp, u32 L, bool scaled /* bucket_sum[] holds (X, Y, 32 ZZ, 32 ZZZ) */) {
   PyrPlan pp;
   auto offA = [&](u32 l) { return nbp - (nbp >> (l - 1)); };                    // level l >= 1 inside a window's A region
   auto offR = [&](u32 l, u32 j) { u32 rs = nbp >> (l + 1); return (nbp - (nbp >> l)) + (rs - (rs >> (j - 1))); };
   auto srcA = [&](u32 l, PyrTask& t) {    // A^l as a source
-    if (l == 0) { t.src_off = ar.bucket_off; t.src_wstride = nbw; t.src_valid = nb; }
+    if (l == 0) { t.src_off = ar.bucket_off; t.src_wstride = nbw; t.src_valid = nb; t.src_scaled = scaled ? 1u : 0u; }
     else { t.src_off = ar.apyr_off + offA(l); t.src_wstride = nbp; t.src_valid = nbp >> l; }
   };
   for (u32 s = 1; s <= L; s++) {
@@ -259,6 +262,14 @@ PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbw, u32 nbp, u32 L) {
         else { r.dst_off = ar.rbuf_off + offR(l, j); r.dst_wstride = nbp; }
         tasks.push_back(r);
       }
+    }
+    if (L == 1 && scaled) {
+      // one level only: U_0 = bucket[1] is read through a task (bucket[1] + nothing) instead of the
+      // copy below, because only tasks convert the scaled form on load
+      PyrTask r; memset(&r, 0, sizeof r);
+      srcA(0, r); r.stride = 1; r.phase = 1; r.count = 1; r.src_valid = std::min(r.src_valid, 2u);
+      r.dst_off = ar.out_off + 1; r.dst_wstride = L + 1;
+      tasks.push_back(r);
     }
     pp.step_max_count.push_back(nbp >> s);
     pp.steps.push_back(tasks);
@@ -413,6 +424,7 @@ struct NegProvider {
 // are left in the arena's out area and copied to d_out (device) + gslot.
 template <class G, class Prov>
 int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
+              bool abi /* d_points are in the C ABI's domain: k_accum1<.., true>, scaled outputs */,
               char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, hipStream_t s_sort, hipStream_t s_acc,
               hipStream_t s_tail, hipEvent_t ev_sorted, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
   // Three queues: the sort passes of this group may run while the previous group accumulates
@@ -423,11 +435,11 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   u32 NBpad = pl.nbins << pl.LB;
   ArenaLayout ar = make_arena(NBpad, nbp, gw, L);
   // pyramid task tables: built and uploaded once per plan shape, then reused
-  std::vector<u32> pkey = {NBpad, pl.nb, pl.nbw, nbp, L, gw};
+  std::vector<u32> pkey = {NBpad, pl.nb, pl.nbw, nbp, L, gw, abi ? 1u : 0u};
   auto pit = ctx->pyr_cache.find(pkey);
   if (pit == ctx->pyr_cache.end()) {
     PyrCacheEntry ent;
-    ent.pp = make_pyr_plan(ar, pl.nb, pl.nbw, nbp, L);
+    ent.pp = make_pyr_plan(ar, pl.nb, pl.nbw, nbp, L, abi);
     std::vector<PyrTask> flat;
     for (auto& s : ent.pp.steps) flat.insert(flat.end(), s.begin(), s.end());
     size_t tb = align_up(flat.size() * sizeof(PyrTask), 256);
@@ -475,6 +487,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     if constexpr (G::CONVERTED_DOMAIN) {
       if (wps == 2) hipLaunchKernelGGL((k_accum1<G, 2>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
       else if (wps == 4) hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      else if (abi) hipLaunchKernelGGL((k_accum1<G, 3, true>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
       else hipLaunchKernelGGL((k_accum1<G, 3>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
     } else {
       hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
@@ -493,14 +506,14 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     {
       u32 per = ctx->opt_seg_records ? (u32)ctx->opt_seg_records : L2_RECORDS;
       u32 nthr = (R + per - 1) / per;
-      hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, per, ik, ip,
+      hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, per, abi ? 1u : 0u, ik, ip,
                          w.arena + (size_t)ar.bucket_off * ptb, ok, op);
       R = 2 * nthr;
       std::swap(ik, ok); std::swap(ip, op);
     }
     for (;;) {
       u32 nwaves = (R + 63) / 64;
-      hipLaunchKernelGGL((k_segwave<G>), dim3((nwaves + 3) / 4), dim3(256), 0, st, R, ik, ip,
+      hipLaunchKernelGGL((k_segwave<G>), dim3((nwaves + 3) / 4), dim3(256), 0, st, R, abi ? 1u : 0u, ik, ip,
                          w.arena + (size_t)ar.bucket_off * ptb, ok, op);
       if (nwaves == 1) break;
       R = 2 * nwaves;
@@ -517,8 +530,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, d_tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
       toff += tasks.size();
     }
-    u32 cthreads = gw * (u32)(ptb / 16);
-    hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, d_copy, 1u, gw, (u32)ptb, w.arena);
+    if (!(L == 1 && abi)) {
+      u32 cthreads = gw * (u32)(ptb / 16);
+      hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, d_copy, 1u, gw, (u32)ptb, w.arena);
+    }
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(d_out, w.arena + (size_t)ar.out_off * ptb, (size_t)gw * (L + 1) * ptb, hipMemcpyDeviceToDevice, st));
@@ -663,16 +678,29 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
       HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_up[k], 0));
     }
     const char* pts = (const char*)d_points + s0 * 64;
+    // Lazy field: either convert the slab's points to the 2^261 domain (one pass, 25 ps per point)
+    // or let k_accum1 consume them as they are (madd_abi: ~100 instructions whenever ANY lane of a
+    // wave opens a segment).  With S = average segment length the second costs P = 1-(1-1/S)^64 of
+    // 110/2058 of the accumulation (68 ps per point and window): cheaper when P * windows < 7.
+    bool abi = false;
     if constexpr (G::CONVERTED_DOMAIN) {
-      hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, s_acc, (const uint4*)pts, (uint4*)d_conv, sn);
-      pts = d_conv;
+      GroupPlan pl0 = make_group_plan(ctx, sn, c, nb, W, groups[0].g0, groups[0].g1, d);
+      double S = std::max(1.0, std::min((double)pl0.L1, (double)sn / (double)nb));
+      double P = 1.0 - std::pow(1.0 - 1.0 / S, 64.0);
+      abi = P * (double)(groups[0].g1 - groups[0].g0) < 7.0 && (ctx->opt_accum_waves == 0 || ctx->opt_accum_waves == 3);
+      if (ctx->opt_abi_points == 1) abi = false;
+      if (ctx->opt_abi_points == 2) abi = (ctx->opt_accum_waves == 0 || ctx->opt_accum_waves == 3);
+      if (!abi) {
+        hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, s_acc, (const uint4*)pts, (uint4*)d_conv, sn);
+        pts = d_conv;
+      }
     }
     for (size_t gi = 0; gi < ng; gi++) {
       const Grp& gr = groups[gi];
       GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, gr.g0, gr.g1, d);
       auto src = make_src(s0, sn);
       hipEvent_t* ev = ctx->evpool.data() + 3 * (k * ng + gi);
-      rc = run_group<G>(ctx, src, pl, nbp, L, pts, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
+      rc = run_group<G>(ctx, src, pl, nbp, L, pts, abi, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
                         s_sort, s_acc, s_tail, ev[0], ev[1], ev[2]);
       if (rc) return rc;
       // the group's non-canonical-scalar flag (first 8 bytes of its workspace) survives the workspace reuse
@@ -1034,6 +1062,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
   else if (!strcmp(name, "seg_records")) { if (value < 0 || value > 64 || value == 1) return LEMSM_ERR_BAD_ARG; ctx->opt_seg_records = value; }
+  else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
   else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }

@@ -66,6 +66,11 @@ struct XYZZ {
     F::mul(r.zzz, W, p.zzz);
   }
 
+  // interface shared with XYZZ29 (k_accum1): this field already works in the ABI's domain
+  static __device__ __forceinline__ void madd_abi(pt& acc, const fe& x2, const fe& y2) { madd(acc, x2, y2); }
+  static __device__ __forceinline__ void unscale(pt&) {}
+  static __device__ __forceinline__ void scale(pt&) {}
+
   // acc += (x2,y2) affine, non-identity input; acc may be anything (madd-2008-s + special cases).
   static __device__ __forceinline__ void madd(pt& acc, const fe& x2, const fe& y2) {
     if (is_identity(acc)) {

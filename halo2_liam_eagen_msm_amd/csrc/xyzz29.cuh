@@ -107,6 +107,59 @@ struct XYZZ29 {
     F::mul(acc.zzz, acc.zzz, PPP);
   }
 
+  // k_accum1's second form of madd: the incoming point is in the C ABI's domain (x2a = x*2^256,
+  // canonical limbs; y2a possibly negated) and the accumulator is (X, Y, 32*ZZ, 32*ZZZ) in the 2^261
+  // domain.  ZZ and ZZZ only ever multiply the incoming coordinates (U2 = x2*ZZ, S2 = y2*ZZZ) and
+  // their own updates (ZZ*PP, ZZZ*PPP), so the factor 32 = 2^261/2^256 rides along for free and the
+  // per-MSM conversion pass over all points (0.43 ms, 2 GB of HBM traffic at 2^24 -- replicated on
+  // every rank of a window-sharded run) is not needed.  What it costs: opening a segment converts
+  // its first point (2 x mul32, ~100 instructions) inside a divergent branch, which a wave pays
+  // whenever ANY lane opens a segment -- so this form is chosen when segments are long or the call
+  // covers few windows (run_group), and the plain form + conversion pass otherwise.
+  static __device__ __forceinline__ void madd_abi(pt& acc, const fe& x2a, const fe& y2a) {
+    if (is_identity(acc)) {
+      F::mul32(acc.x, x2a); F::mul32(acc.y, y2a); F::set_c266(acc.zz); F::set_c266(acc.zzz);
+      return;
+    }
+    fe U2, S2, P, R, PP;
+    F::mul(U2, x2a, acc.zz);
+    F::mul(S2, y2a, acc.zzz);
+    F::sub(P, U2, acc.x);
+    F::sub(R, S2, acc.y);
+    F::sqr(PP, P);
+    if (pp_is_zero(PP)) {                 // same x: doubling or cancellation
+      if (F::is_zero_mod(R)) {
+        // (only a and res have their address taken, see madd)
+        pt a, res; F::from_abi(a.x, x2a); F::from_abi(a.y, y2a); F::set_one(a.zz); F::set_one(a.zzz);
+        dbl_impl<true>(res, a);
+        F::from_abi(res.zz, res.zz); F::from_abi(res.zzz, res.zzz);   // times 32
+        acc = res;
+      } else set_identity(acc);
+      return;
+    }
+    fe PPP, Q, t, nY;
+    F::mul(PPP, P, PP);
+    F::mul(Q, acc.x, PP);
+    hi_term(t, PPP, Q);
+    F::neg(nY, acc.y);
+    F::sqr_addhi(acc.x, R, t);                     // X3 = R^2 - PPP - 2Q
+    F::sub(t, Q, acc.x);
+    F::mul2(acc.y, R, t, nY, PPP);                 // Y3 = R(Q - X3) - Y1*PPP
+    F::mul(acc.zz, acc.zz, PP);
+    F::mul(acc.zzz, acc.zzz, PPP);
+  }
+  // (X, Y, 32 ZZ, 32 ZZZ) <-> plain XYZZ.  In the ABI form k_accum1 writes what it holds (its flush is
+  // a divergent branch too) and the consumers convert on load: edge records in k_segreduce, bucket
+  // sums in the first pyramid step; bucket_sum[] then holds the scaled form throughout.
+  static __device__ __forceinline__ void unscale(pt& p) {
+    if (is_identity(p)) return;
+    F::div32(p.zz, p.zz); F::div32(p.zzz, p.zzz);
+  }
+  static __device__ __forceinline__ void scale(pt& p) {
+    if (is_identity(p)) return;
+    F::from_abi(p.zz, p.zz); F::from_abi(p.zzz, p.zzz);
+  }
+
   // acc += q (both XYZZ, any inputs)
   static __device__ __forceinline__ void add(pt& acc, const pt& q) {
     if (is_identity(q)) return;

@@ -81,7 +81,10 @@ size_t lemsm_last_bad_index(const lemsm_ctx* ctx);
    "host_slab_bits" (host-pointer entries: log2 of the slab of pairs uploaded while the previous
    slab is being accumulated; 0 = auto = 21), "slab_bits" (device-pointer entries: log2 of the
    slab of pairs one pass of the pipeline covers; 0 = auto = 24, smaller values are a test knob),
-   "seg_records" (edge records per thread at the first reduction level, 0 = auto = 8). */
+   "seg_records" (edge records per thread at the first reduction level, 0 = auto = 8),
+   "abi_points" (lazy arithmetic: 1 = convert the points to the kernels' domain in a pass of their
+   own, 2 = let the accumulation consume them as passed in, 0 = choose by segment length and window
+   count). */
 int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value);
 /* Device-time (ms, from HIP events on the context's stream) of the last MSM call: whole
    pipeline in [0], the dominant accumulate kernel in [1], its launch count in [2]. */

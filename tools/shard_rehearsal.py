@@ -18,7 +18,9 @@ q = np.zeros(8, np.uint64); fp = 0x30644E72E131A029B85045B68181585D97816A916871C
 q[:4] = np.frombuffer(((1 << 256) % fp).to_bytes(32, "little"), np.uint64); q[4:] = np.frombuffer(((2 << 256) % fp).to_bytes(32, "little"), np.uint64)
 dp = ctx.gen_walk(0, q, n)
 ds = ctx.to_device(sc)
+ctx.set_option("window_bits", 16)   # what bench.py pins for window sharding (16 windows split evenly)
 W, rec = ctx.msm_plan(0, n)
+ctx.set_option("window_bits", 0)
 
 def best(fn, reps=5):
     fn(); b = 1e9
@@ -28,7 +30,9 @@ def best(fn, reps=5):
 
 for G in (1, 2, 4, 8):
     w1 = W // G
+    ctx.set_option("window_bits", 16)
     tw = best(lambda: ctx.msm_partial_device(0, ds.ptr, dp.ptr, n, 0, w1))
+    ctx.set_option("window_bits", 0)
     m = n // G
     tp = best(lambda: ctx.msm_partial_device(0, ds.ptr, dp.ptr, m, 0, ctx.msm_plan(0, m)[0]))
     print("2^%d over %d ranks: window-sharded rank %.2f ms (%d of %d windows, all points) | point-sharded rank %.2f ms (2^%d points, %d windows)"
