@@ -183,7 +183,6 @@ __global__ __launch_bounds__(256) void k_segwave(u32 R, u32 scaled, const u32* _
   // neighbours across the wave boundary
   u32 prev_glob = wbase > 0 ? in_key[wbase - 1] : KEY_NONE;
   u32 next_glob = wbase + 64 < R ? in_key[wbase + 64] : KEY_NONE;
-  u32 kprev = __shfl_up(key, 1); if (lane == 0) kprev = prev_glob;
   u32 knext = __shfl_down(key, 1); if (lane == 63) knext = next_glob;
   const u32 key0 = __shfl(key, 0);
 #pragma unroll 1
