@@ -375,6 +375,53 @@ def compute_lhs_witness(scalars, pts, base: int, curve="grumpkin", ctx: Optional
     return (ctx or default_context()).lhs_msm(curve, scalars, pts, base, True)
 
 
+def _neg_affine_raw(curve_id: int, pts: np.ndarray) -> np.ndarray:
+    """-(x, y) = (x, p - y) on raw Montgomery limbs (negation commutes with the Montgomery factor);
+    the identity (0, 0) stays (0, 0)."""
+    fp = ORDER[GRUMPKIN] if curve_id == BN254_G1 else ORDER[BN254_G1]   # base field of one = scalar field of the other
+    out = np.array(pts, np.uint64).reshape(-1, 8).copy()
+    for r in out:
+        y = int.from_bytes(r[4:].tobytes(), "little")
+        if y:
+            r[4:] = np.frombuffer(((fp - y) % fp).to_bytes(32, "little"), np.uint64)
+    return out
+
+
+def compute_lhs_witness_inputs(scalars, pts, base: int, curve="grumpkin", ctx: Optional[Context] = None):
+    """(carry, tmp_lists): the point lists the reference collects in `tmp` and hands to
+    compute_divisor_witness, one per iteration of its digit loop, MSB first
+    (src/argument_witness_calc.rs:108-127; the reference returns the resulting vector reversed, :129):
+
+        tmp_i = [-carry_{i-1}] * base   (only if carry_{i-1} is not the identity, :112-116)
+              + [digit_{j,i} * P_j for every j whose digit is non-zero, in order of j]   (:120-124)
+              + [-carry_i]                                                               (:127)
+
+    as affine raw-Montgomery limbs, shape (len, 8), identity = (0, 0).  Every group operation behind
+    them runs on the GPU -- the per-digit carries (lemsm_lhs_msm), the table of affine multiples
+    (lemsm_precompute_multiplicities_affine, which also turns the carries affine) and the digit
+    matrix (lemsm_negbase_decompose_batch); what is left here is indexing, so the Rust side can
+    build `tmp` without a single serial EC addition.  The polynomial step
+    compute_divisor_witness itself stays on the Rust side (out of scope)."""
+    c = ctx or default_context()
+    cid = _curve_id(curve)
+    carry, carries = c.lhs_msm(cid, scalars, pts, base, True)
+    d = carries.shape[0]
+    digits = c.negbase_decompose_batch(scalars, base, d)                  # (n, d), LSB first
+    table = c.precompute_multiplicities_affine(cid, pts, base)            # (n, base-1, 8)
+    neg_carries = _neg_affine_raw(cid, c.precompute_multiplicities_affine(cid, carries, 2).reshape(d, 8))
+    tmp_lists = []
+    for i in range(d):
+        dig = digits[:, d - 1 - i].astype(np.int64)                       # the reference reverses the digits (:101)
+        nz = np.nonzero(dig)[0]
+        parts = []
+        if i > 0 and neg_carries[i - 1].any():
+            parts.append(np.repeat(neg_carries[i - 1][None, :], base, axis=0))
+        parts.append(table[nz, dig[nz] - 1])                              # precomputed_points[j][id_by_digit(digit)]
+        parts.append(neg_carries[i][None, :])
+        tmp_lists.append(np.concatenate(parts, axis=0))
+    return carry, tmp_lists
+
+
 def negbase_decompose(x: int, base: int, ctx: Optional[Context] = None) -> List[int]:
     """Digits LSB first, no padding, [] for 0 (src/negbase_utils.rs:20-36).  x >= 0 here: the
     reference's callers only pass non-negative scalars (src/argument_witness_calc.rs:99)."""

@@ -416,6 +416,46 @@ def test_lhs_reference_test_shape(fctx):
     assert canon(c, a) == c.canonical(c.mul(k, c.raw_to_affine(pt[0].tobytes())))
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("base,n", [(5, 60), (16, 45), (3, 30)])
+def test_lhs_witness_point_lists_match_reference_loop(ctx, curve, base, n):
+    """api.compute_lhs_witness_inputs rebuilds the `tmp` lists of src/argument_witness_calc.rs:108-127
+    from GPU outputs by indexing only; compared point by point with a big-int restatement of that loop,
+    and each list sums to the identity (what makes it a principal divisor)."""
+    rng = pyref.SplitMix64(4100 + base + n + curve.cid)
+    pts = pyref.gen_points(curve, rng, n)
+    sc = pyref.gen_scalars_half(rng, n, curve.order)
+    sc[0] = 0; sc[1] = 1                                       # empty and one-digit decompositions
+    d = pyref.num_digits(curve.order, base)
+    # the reference's loop, restated on integers
+    digs = [pyref.negbase_digits_padded(x, base, d)[::-1] for x in sc]
+    carry = None; expect = []
+    for i in range(d):
+        tmp = []
+        if carry is not None:
+            tmp += [curve.neg(carry)] * base
+        carry = curve.mul(base, curve.neg(carry)) if carry is not None else None
+        for j in range(n):
+            k = digs[j][i]
+            if k:
+                m = curve.mul(k, pts[j]); tmp.append(m); carry = curve.add(carry, m)
+        tmp.append(curve.neg(carry) if carry is not None else None)
+        expect.append(tmp)
+    sc_b = np.frombuffer(pyref.scalars_to_bytes(sc), np.uint8).reshape(-1, 32)
+    pj = np.array([np.frombuffer(curve.affine_to_jacobian_raw(p_, 1 + rng.next256() % (curve.fp - 1)), np.uint64) for p_ in pts])
+    got_carry, lists = api.compute_lhs_witness_inputs(sc_b, pj, base, curve.cid, ctx)
+    assert canon(curve, got_carry) == curve.canonical(carry)
+    assert len(lists) == d
+    for i in range(d):
+        assert lists[i].shape == (len(expect[i]), 8), i
+        for k, e in enumerate(expect[i]):
+            assert lists[i][k].tobytes() == curve.affine_to_raw(e), (i, k)
+        acc = None
+        for row in lists[i]:
+            acc = curve.add(acc, curve.raw_to_affine(row.tobytes()))
+        assert acc is None, i
+
+
 def test_lhs_errors(ctx):
     c = pyref.GRUMPKIN
     pts = cref.aff_to_jac(c.cid, cref.gen_points(c.cid, 5, 5))
