@@ -40,3 +40,25 @@ def test_no_oracle_in_product():
                 if f.endswith(".py"):
                     assert not re.search(r"^\s*(import oracle|from oracle)", text, re.M), f
                 assert "liblemsm_oracle" not in text, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/lemsm.h compiles as C99 (no torch / C++ types in the signatures)
+    and a C program links against the library and calls an entry that needs no GPU"""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text(
+        '#include "lemsm.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  uint32_t d = 0; uint64_t out[12]; uint64_t two[24] = {0};\n"
+        "  if (lemsm_num_digits(LEMSM_GRUMPKIN, 5, &d) != LEMSM_OK) return 1;\n"
+        "  if (lemsm_jacobian_sum(LEMSM_BN254_G1, two, 2, out) != LEMSM_OK) return 2;   /* identity + identity */\n"
+        "  for (int i = 0; i < 12; i++) if (out[i]) return 3;\n"
+        '  printf("%u\\n", d); return 0;\n}\n')
+    exe = tmp_path / "use"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-llemsm", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)]).decode().strip()
+    from oracle import pyref
+    assert int(out) == pyref.num_digits(pyref.GRUMPKIN.order, 5)
