@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
   u32 first_key = KEY_NONE;
 
   typename G::pt acc; G::set_identity(acc);
+  bool empty = true;          // acc == identity (tracked so that the loop tests a flag, not nine limbs)
 
   auto flush = [&](u32 seg_end) {
     bool complete = (seg_begin == kbeg) && (seg_end == kend);
@@ -80,11 +81,11 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
       flush(i);
       do { key++; kend = bucket_start[key + 1]; } while (i >= kend);
       kbeg = i; seg_begin = i;
-      G::set_identity(acc);
+      G::set_identity(acc); empty = true;
     }
     if (!G::aff_is_identity(px, py)) {
       F::cneg(py, py, (e >> 31) != 0);
-      if (ABI) G::madd_abi(acc, px, py); else G::madd(acc, px, py);
+      if (ABI) G::madd_abi(acc, px, py, empty); else G::madd(acc, px, py, empty);
     }
   }
   flush(end);

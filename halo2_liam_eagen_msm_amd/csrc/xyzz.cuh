@@ -67,7 +67,8 @@ struct XYZZ {
   }
 
   // interface shared with XYZZ29 (k_accum1): this field already works in the ABI's domain
-  static __device__ __forceinline__ void madd_abi(pt& acc, const fe& x2, const fe& y2) { madd(acc, x2, y2); }
+  static __device__ __forceinline__ void madd_abi(pt& acc, const fe& x2, const fe& y2, bool& empty) { madd(acc, x2, y2, empty); }
+  static __device__ __forceinline__ void madd(pt& acc, const fe& x2, const fe& y2, bool& empty) { madd(acc, x2, y2); empty = is_identity(acc); }
   static __device__ __forceinline__ void unscale(pt&) {}
   static __device__ __forceinline__ void scale(pt&) {}
 

@@ -20,7 +20,9 @@ struct XYZZ29 {
   typedef F F_;
   typedef typename F::fe fe;
   static constexpr bool CONVERTED_DOMAIN = true;   // coordinates are x*2^261, see field29.cuh
-  static __device__ __forceinline__ bool aff_is_identity(const fe& x, const fe& y) { return F::limbs_zero(x) && F::limbs_zero(y); }
+  // (0,0) is the identity.  Both curves have prime order, so no valid point has y == 0: testing y
+  // alone is exact for valid input and halves the per-entry cost of the test in k_accum1.
+  static __device__ __forceinline__ bool aff_is_identity(const fe&, const fe& y) { return F::limbs_zero(y); }
   struct pt { fe x, y, zz, zzz; };
 
   static __device__ __forceinline__ void set_identity(pt& p) {
@@ -73,11 +75,21 @@ struct XYZZ29 {
 
   // acc += (x2, y2): affine, non-identity, 2^261-domain normalised coordinates; y2 may carry
   // a negation (|limb| < 2^29).
-  static __device__ __forceinline__ void madd(pt& acc, const fe& x2, const fe& y2) {
-    if (is_identity(acc)) {
+  // `empty` (k_accum1 only): the caller's record of acc == identity, so that the hot loop tests one
+  // flag instead of nine limbs; madd keeps it current (set on cancellation, cleared otherwise).
+  static __device__ __forceinline__ void madd(pt& acc, const fe& x2, const fe& y2, bool& empty) {
+    if (empty) {
       acc.x = x2; acc.y = y2; F::wnorm(acc.y); F::set_one(acc.zz); F::set_one(acc.zzz);
+      empty = false;
       return;
     }
+    madd_nonempty(acc, x2, y2, empty);
+  }
+  static __device__ __forceinline__ void madd(pt& acc, const fe& x2, const fe& y2) {
+    bool empty = is_identity(acc);
+    madd(acc, x2, y2, empty);
+  }
+  static __device__ __forceinline__ void madd_nonempty(pt& acc, const fe& x2, const fe& y2, bool& empty) {
     fe U2, S2, P, R, PP;
     F::mul(U2, x2, acc.zz);
     F::mul(S2, y2, acc.zzz);
@@ -92,7 +104,7 @@ struct XYZZ29 {
         pt a, res; a.x = x2; a.y = y2; F::set_one(a.zz); F::set_one(a.zzz);
         dbl_impl<true>(res, a);
         acc = res;
-      } else set_identity(acc);
+      } else { set_identity(acc); empty = true; }
       return;
     }
     fe PPP, Q, t, nY;
@@ -116,9 +128,10 @@ struct XYZZ29 {
   // its first point (2 x mul32, ~100 instructions) inside a divergent branch, which a wave pays
   // whenever ANY lane opens a segment -- so this form is chosen when segments are long or the call
   // covers few windows (run_group), and the plain form + conversion pass otherwise.
-  static __device__ __forceinline__ void madd_abi(pt& acc, const fe& x2a, const fe& y2a) {
-    if (is_identity(acc)) {
+  static __device__ __forceinline__ void madd_abi(pt& acc, const fe& x2a, const fe& y2a, bool& empty) {
+    if (empty) {
       F::mul32(acc.x, x2a); F::mul32(acc.y, y2a); F::set_c266(acc.zz); F::set_c266(acc.zzz);
+      empty = false;
       return;
     }
     fe U2, S2, P, R, PP;
@@ -134,7 +147,7 @@ struct XYZZ29 {
         dbl_impl<true>(res, a);
         F::from_abi(res.zz, res.zz); F::from_abi(res.zzz, res.zzz);   // times 32
         acc = res;
-      } else set_identity(acc);
+      } else { set_identity(acc); empty = true; }
       return;
     }
     fe PPP, Q, t, nY;
