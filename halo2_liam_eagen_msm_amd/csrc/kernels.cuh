@@ -262,25 +262,24 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
   }
 }
 
-template <class Dec>
+template <class Dec, int STG /* entries staged per block: STAGE, or 2*STAGE at 512 bins per window (keeps the runs 64 bytes) */>
 __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
                                                   const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
                                                   u32* __restrict__ entries) {
   __shared__ u32 lstart[BW_MAX + 1];
-  __shared__ u32 gbase[BW_MAX];
+  __shared__ u32 delta[BW_MAX];        // global position of a bin's run minus its position in the staging buffer
   __shared__ u32 lcur[BW_MAX];
   __shared__ u32 wsum[4];
-  __shared__ u32 stage[STAGE];
-  __shared__ uint16_t sbin[STAGE];
+  __shared__ u32 stage[STG];           // jl:13 | local:7 | sign:1 | bin:9  (jl = index inside the block's range)
   // grid = (windows, ranges): neighbouring blocks work on different windows, so the claim atomics
   // of concurrently running blocks spread over gw x BW addresses instead of hammering BW of them
   const u32 tid = threadIdx.x, wl = blockIdx.x, r = blockIdx.y, w = pl.w0 + wl;
   const u32 lmask = (1u << pl.LB) - 1u;
   u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
-  // Issue every load of the block up front -- the digit column (STAGE/256 per thread) and this
+  // Issue every load of the block up front -- the digit column (STG/256 per thread) and this
   // block's bin counts -- so that their latencies overlap each other and the claim atomics
   // (a rolled loop waits out one memory latency per entry: measured 3x slower).
-  constexpr int PER = STAGE / 256;
+  constexpr int PER = STG / 256;
   u32 bk[PER], sg[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
@@ -298,24 +297,22 @@ __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u
   const u32 total = total0 + total1;
   lstart[tid] = off0; lstart[tid + 256u] = off1;
   if (tid == 255) lstart[BW_MAX] = total;
-  gbase[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) : 0u;
-  gbase[tid + 256u] = cnt1 ? bin_start[wl * pl.BW + tid + 256u] + atomicAdd(&bin_cursor[wl * pl.BW + tid + 256u], cnt1) : 0u;
+  delta[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) - off0 : 0u;
+  delta[tid + 256u] = cnt1 ? bin_start[wl * pl.BW + tid + 256u] + atomicAdd(&bin_cursor[wl * pl.BW + tid + 256u], cnt1) - off1 : 0u;
   lcur[tid] = 0; lcur[tid + 256u] = 0;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     if (bk[k]) {
-      u32 j = j0 + tid + 256u * k;
       u32 kk = bk[k] - 1u, b = kk >> pl.LB;
       u32 q = lstart[b] + atomicAdd(&lcur[b], 1u);
-      stage[q] = j | ((kk & lmask) << 24) | (sg[k] << 31);
-      sbin[q] = (uint16_t)b;
+      stage[q] = (tid + 256u * k) | ((kk & lmask) << 13) | (sg[k] << 20) | (b << 21);
     }
   }
   __syncthreads();
   for (u32 q = tid; q < total; q += 256) {
-    u32 b = sbin[q];
-    entries[gbase[b] + (q - lstart[b])] = stage[q];
+    u32 v = stage[q];
+    entries[delta[v >> 21] + q] = (j0 + (v & 0x1fffu)) | (((v >> 13) & 127u) << 24) | (((v >> 20) & 1u) << 31);
   }
 }
 

@@ -86,7 +86,7 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0;
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   size_t bad_index = 0;
@@ -354,6 +354,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   spb = std::max(256u, std::min((u32)STAGE, spb));
   spb = (spb + 255) / 256 * 256;
   if (n >= (1u << 16)) spb = STAGE;     // long (block, bin) runs -> full-line writes
+  if (n >= (1u << 16) && d == 0 && ctx->opt_stage2x == 2) spb = 2 * STAGE;   // A/B knob: 64-byte runs at 512 bins per window; measured slower (fewer resident blocks), profiles/r01/y_scatter1_staging_ab.txt
   g.spb = spb;
   g.nblk1 = (n + spb - 1) / spb;
   if (g.nblk1 == 0) g.nblk1 = 1;
@@ -461,7 +462,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   typename Prov::Dec dec;
   { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.signbm, w.block_counts, w.bin_total, w.err, dec); if (rcp) return rcp; }
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
-  hipLaunchKernelGGL((k_scatter1<typename Prov::Dec>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
+  if (pl.spb > STAGE)
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 2 * STAGE>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
+  else
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
   // pass 2 only where a bin holds more than one bucket (LB > 0); with <= 256 buckets per window
   // (negabase digits) pass 1 already sorts exactly: bins are buckets
   const u32* d_sorted = w.entries;
@@ -1063,6 +1067,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
   else if (!strcmp(name, "seg_records")) { if (value < 0 || value > 64 || value == 1) return LEMSM_ERR_BAD_ARG; ctx->opt_seg_records = value; }
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
+  else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
   else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }
