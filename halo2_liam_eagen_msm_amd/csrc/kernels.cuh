@@ -390,10 +390,9 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
                                                   u32* __restrict__ bucket_cursor, u32* __restrict__ sorted) {
   __shared__ u32 hist[256];
   __shared__ u32 lstart[257];
-  __shared__ u32 gbase[256];
+  __shared__ u32 delta[256];          // global position of a bucket's run minus its position in the staging buffer
   __shared__ u32 wsum[4];
-  __shared__ u32 stage[STAGE2];
-  __shared__ uint8_t sloc[STAGE2];
+  __shared__ u32 stage[STAGE2];       // the pass-1 entry itself: its local-bucket bits say which run it belongs to
   u32 bin, off, end;
   if (!locate_tile(tile_info, bin, off, end)) return;
   const u32 tid = threadIdx.x;
@@ -415,22 +414,20 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
   lstart[tid] = o;
   if (tid == 255) lstart[256] = total;
   u32 key = (bin << pl.LB) + tid;
-  gbase[tid] = cnt ? bucket_start[key] + atomicAdd(&bucket_cursor[key], cnt) : 0u;
+  delta[tid] = cnt ? bucket_start[key] + atomicAdd(&bucket_cursor[key], cnt) - o : 0u;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     u32 i = off + tid + 256u * k;
     if (i < end) {
       u32 l = (e[k] >> 24) & 127u;
-      u32 q = lstart[l] + rk[k];
-      stage[q] = e[k] & 0x80ffffffu;
-      sloc[q] = (uint8_t)l;
+      stage[lstart[l] + rk[k]] = e[k];
     }
   }
   __syncthreads();
   for (u32 q = tid; q < total; q += 256) {
-    u32 l = sloc[q];
-    sorted[gbase[l] + (q - lstart[l])] = stage[q];
+    u32 v = stage[q];
+    sorted[delta[(v >> 24) & 127u] + q] = v & 0x80ffffffu;
   }
 }
 
