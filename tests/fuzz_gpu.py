@@ -32,7 +32,8 @@ def neg_points(curve, pts):
 
 
 def make_case(rng, curve):
-    n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 3000), rng.integers(3000, 70000)]))
+    n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 3000), rng.integers(3000, 70000), rng.integers(3000, 70000),
+                        rng.integers(70000, 1 << 20)]))
     base_pts = cref.gen_points(curve.cid, int(rng.integers(1, 1 << 30)), min(n, int(rng.integers(1, 400))))
     shape = rng.choice(["uniform", "few_points", "pairs_cancel", "identities", "equal_scalars", "tiny_scalars", "top_scalars"])
     idx = rng.integers(0, base_pts.shape[0], n)
@@ -61,18 +62,22 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = api.Context(0)
     t0 = time.time(); cases = 0
-    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "seg_records", "accum_waves"]
+    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "seg_records", "accum_waves", "host_slab_bits", "groups"]
     while time.time() - t0 < secs:
         curve = CURVES[int(rng.integers(0, 2))]
         opts = {"window_bits": int(rng.choice([0, 0, 2, 3, 5, 8, 11, 13, 16, 17])), "chunk": int(rng.choice([0, 0, 1, 3, 17, 64, 300])),
                 "tile": int(rng.choice([0, 0, 256, 1000])), "field": int(rng.choice([0, 0, 1])), "abi_points": int(rng.integers(0, 3)),
                 "slab_bits": int(rng.choice([0, 0, 12, 14])), "seg_records": int(rng.choice([0, 2, 5, 8, 16])),
-                "accum_waves": int(rng.choice([0, 0, 2, 4]))}
+                "accum_waves": int(rng.choice([0, 0, 2, 4])), "host_slab_bits": int(rng.choice([0, 12, 13, 16])),
+                "groups": 0}
+        host_entry = rng.random() < 0.5
+        if not host_entry:
+            opts["groups"] = int(rng.choice([0, 0, 2, 3]))     # pipelined window groups: device-pointer entries only
         for k in names:
             ctx.set_option(k, opts[k])
         if rng.random() < 0.75:
             n, shape, sc, pts = make_case(rng, curve)
-            got = ctx.msm(curve.cid, sc, pts) if rng.random() < 0.5 else None
+            got = ctx.msm(curve.cid, sc, pts) if host_entry else None
             if got is None:
                 ds, dp = ctx.to_device(sc), ctx.to_device(pts)
                 got = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
