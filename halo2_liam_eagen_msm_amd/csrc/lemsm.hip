@@ -87,6 +87,7 @@ struct lemsm_ctx {
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
   long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0;
+  bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   size_t bad_index = 0;
@@ -768,6 +769,24 @@ void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W window sums */, 
   G::to_jacobian(acc, out);
 }
 
+// Whole-MSM host tail straight from the per-window records [total, U_0..U_{L-1}]:
+//   sum_w 2^(cw) (total_w + sum_l 2^l U_{w,l}) = sum_j 2^j T_j  with  T_{cw+l} = U_{w,l} (+ total_w at l = 0),
+// one Horner pass of c(W-1)+L doublings instead of W separate L-step passes followed by a cW-step one
+// (l <= L-1 = c-2 < c, so the positions never collide).
+template <class P64>
+void msm_combine_raw_t(const MsmPlan& mp, const host::pt* recs /* W x (L+1) */, u64 out[12]) {
+  typedef host::HG<P64> G;
+  host::pt acc = G::identity();
+  for (int j = (int)(mp.c * (mp.W - 1) + mp.L) - 1; j >= 0; j--) {
+    acc = G::dbl(acc);
+    u32 w = (u32)j / mp.c, l = (u32)j % mp.c;
+    const host::pt* r = recs + (size_t)w * (mp.L + 1);
+    if (l < mp.L) acc = G::add(acc, r[1 + l]);
+    if (l == 0) acc = G::add(acc, r[0]);
+  }
+  G::to_jacobian(acc, out);
+}
+
 template <class P64>
 void jacobian_sum_t(const uint64_t* jac, size_t count, uint64_t out[12]) {
   typedef host::HG<P64> G;
@@ -788,6 +807,7 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   std::vector<host::pt> recs;
   int rc = run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, recs);
   if (rc) return rc;
+  if (ctx->want_raw_records) { out.swap(recs); return LEMSM_OK; }   // whole-MSM entry: one fused Horner (msm_combine_raw_t)
   // this rank's share of the host tail: S_w = total + sum_l 2^l U_l for its own windows
   out.resize(we - wb);
   for (u32 w = 0; w < we - wb; w++) out[w] = window_sum<P64>(recs.data() + (size_t)w * (mp.L + 1), mp.L);
@@ -1122,10 +1142,12 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   HIPCHK(ctx, hipSetDevice(ctx->device));
   MsmPlan mp = make_msm_plan(ctx, curve, n);
   std::vector<host::pt> recs;
+  ctx->want_raw_records = true;
   rc = msm_partial_dispatch(ctx, curve, d_scalars, d_points, n, 0, mp.W, recs);
+  ctx->want_raw_records = false;
   if (rc) return rc;
-  if (curve == LEMSM_BN254_G1) msm_combine_t<host::FqParams64>(mp, recs.data(), out);
-  else msm_combine_t<host::FrParams64>(mp, recs.data(), out);
+  if (curve == LEMSM_BN254_G1) msm_combine_raw_t<host::FqParams64>(mp, recs.data(), out);
+  else msm_combine_raw_t<host::FrParams64>(mp, recs.data(), out);
   return LEMSM_OK;
 }
 
