@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tas
 }
 
 // ------------------------------------------------------------------------------------
-// ABI points (x*2^256, canonical) -> the hot kernels' domain (x*2^261, canonical), once per MSM.
+// ABI points (x*2^256, canonical) -> the hot kernels' domain (x*2^261, canonical): one pass per slab,
+// only when k_accum1 runs in its plain form (short segments; see XYZZ29::madd_abi for the other form).
 // (0,0) (the identity) maps to (0,0).
 // ------------------------------------------------------------------------------------
 template <class F29>

@@ -157,7 +157,7 @@ u32 choose_c(const lemsm_ctx* ctx, size_t n) {
   // 17-bit windows (15 windows of 2^16 buckets, 512 coarse bins each, one window group) from 2^24
   // points per slab: 6 % less accumulation, 0.5 ms more sort + tail -> 3 % faster end to end at
   // 2^24, a wash below (profiles/r01/p_c16_vs_c17_one_group.txt).  Window-sharded multi-GPU runs
-  // pin 16 (dist.py): 16 windows split evenly over 2/4/8 ranks, 15 do not.
+  // pin 16 (bench.py sets window_bits = 16 for them): 16 windows split evenly over 2/4/8 ranks, 15 do not.
   if (lg >= 24) return 17;
   int c = (int)lg - 3;
   if (c < 3) c = 3;
