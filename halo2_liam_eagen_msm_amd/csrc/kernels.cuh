@@ -265,15 +265,25 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
 template <class Dec, int STG /* entries staged per block: STAGE, or 2*STAGE at 512 bins per window (keeps the runs 64 bytes) */>
 __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
                                                   const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
-                                                  u32* __restrict__ entries) {
+                                                  u32* __restrict__ entries, u32 xcd_windows /* 1-D grid, one XCD per window */) {
   __shared__ u32 lstart[BW_MAX + 1];
   __shared__ u32 delta[BW_MAX];        // global position of a bin's run minus its position in the staging buffer
   __shared__ u32 lcur[BW_MAX];
   __shared__ u32 wsum[4];
   __shared__ u32 stage[STG];           // jl:13 | local:7 | sign:1 | bin:9  (jl = index inside the block's range)
-  // grid = (windows, ranges): neighbouring blocks work on different windows, so the claim atomics
-  // of concurrently running blocks spread over gw x BW addresses instead of hammering BW of them
-  const u32 tid = threadIdx.x, wl = blockIdx.x, r = blockIdx.y, w = pl.w0 + wl;
+  // Block -> (window, range).  With >= 8 windows (1-D grid of 8 * ceil(gw/8) * nblk1 blocks) all blocks of
+  // one window carry the same blockIdx.x % 8, i.e. run on one XCD (guide T1: the label groups blocks by XCD):
+  // neighbouring (block, bin) runs of a window are then written through ONE L2 and merge into whole lines --
+  // with the runs of a window spread over all XCDs, 61 % of this kernel's write requests were 32-byte halves
+  // (profiles/r01/x_pmc_sort_kernels_2p24.txt).  Fewer windows: grid = (windows, ranges) as before.
+  const u32 tid = threadIdx.x;
+  u32 wl, r;
+  if (xcd_windows) {
+    const u32 wpx = (pl.w1 - pl.w0 + 7u) >> 3, slot = blockIdx.x >> 3;
+    wl = (blockIdx.x & 7u) + 8u * (slot % wpx); r = slot / wpx;
+    if (wl >= pl.w1 - pl.w0) return;
+  } else { wl = blockIdx.x; r = blockIdx.y; }
+  const u32 w = pl.w0 + wl;
   const u32 lmask = (1u << pl.LB) - 1u;
   u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
   // Issue every load of the block up front -- the digit column (STG/256 per thread) and this

@@ -86,7 +86,7 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0;
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
@@ -463,10 +463,13 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   typename Prov::Dec dec;
   { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.signbm, w.block_counts, w.bin_total, w.err, dec); if (rcp) return rcp; }
   hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, st, pl, w.bin_total, w.bin_start, w.tile_prefix, w.meta);
+  // >= 8 windows: 1-D grid, one XCD per window (see the kernel); else (windows, ranges)
+  const u32 xw = (gw >= 8 && ctx->opt_xcd_windows != 1) ? 1u : 0u;
+  dim3 g1 = xw ? dim3(8u * ((gw + 7) / 8) * pl.nblk1) : dim3(gw, pl.nblk1);
   if (pl.spb > STAGE)
-    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 2 * STAGE>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 2 * STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
   else
-    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE>), dim3(gw, pl.nblk1), dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries);
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
   // pass 2 only where a bin holds more than one bucket (LB > 0); with <= 256 buckets per window
   // (negabase digits) pass 1 already sorts exactly: bins are buckets
   const u32* d_sorted = w.entries;
@@ -1088,6 +1091,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "seg_records")) { if (value < 0 || value > 64 || value == 1) return LEMSM_ERR_BAD_ARG; ctx->opt_seg_records = value; }
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
+  else if (!strcmp(name, "xcd_windows")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_xcd_windows = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
   else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }
