@@ -20,7 +20,8 @@ enum { META_M = 0, META_TILES = 1, META_WORDS = 4 };
 // edge record (at most two per thread: first and last segment) for the next level.
 // ------------------------------------------------------------------------------------
 template <class G, int WPS /* waves per SIMD the register budget is sized for */,
-          bool ABI = false /* points in the C ABI's domain, accumulator and outputs in the scaled form: G::madd_abi */>
+          bool ABI = false /* points in the C ABI's domain, accumulator and outputs in the scaled form: G::madd_abi */,
+          bool RING = false /* entries reach the lanes through a per-wave LDS ring filled by global_load_lds (needs L1 % 16 == 0) */>
 __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __restrict__ sorted,
                                                 const u32* __restrict__ bucket_start, const u32* __restrict__ meta,
                                                 const uint4* __restrict__ points, char* __restrict__ bucket_sum,
@@ -64,7 +65,30 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
     }
   };
 
-  u32 e_next = sorted[start];
+  // Entry stream.  Plain form: every lane walks its own 1-KB chunk with 4-byte loads; 768 lanes per CU keep
+  // 98 KB of lines live against a 32 KB L1, so a 128-byte line is re-fetched ~8 times from HBM before its 32
+  // entries are used (8 GB per 2^24-point launch).  RING form: a lane's next 16 entries (64 B, half a line) go
+  // straight from memory into a per-wave LDS ring (global_load_lds_dwordx4, no VGPRs), two blocks deep; the
+  // lane then takes one ds_read_b32 per entry.  A wave only ever reads what it staged itself, so its own
+  // s_waitcnt vmcnt(0) orders the DMA before the reads; a block is overwritten 16 iterations after its last read.
+  __shared__ u32 ering[RING ? 4 : 1][2][4][64][RING ? 4 : 1];
+  const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  auto ring_fill = [&](u32 blk) {       // stage entries [start + 16 blk, start + 16 blk + 16) of every lane of this wave
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sorted + start + 16u * blk + 4u * k),
+                                       (__attribute__((address_space(3))) void*)&ering[wv][blk & 1u][k][0][0], 16, 0, 0);
+  };
+  auto ring_read = [&](u32 rel) -> u32 { return ering[wv][(rel >> 4) & 1u][(rel >> 2) & 3u][lane][rel & 3u]; };
+  u32 e_next;
+  if constexpr (RING) {
+    ring_fill(0);
+    if (pl.L1 > 16) ring_fill(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    e_next = ring_read(0);
+  } else {
+    e_next = sorted[start];
+  }
   fe nx, ny;
   { const uint4* p = points + (size_t)(e_next & 0xffffffu) * 4; F::load(nx, p); F::load(ny, p + 2); }
 
@@ -73,7 +97,14 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
   for (u32 i = start; i < end; i++) {
     u32 e = e_next; fe px = nx, py = ny;
     if (i + 1 < end) {
-      e_next = sorted[i + 1];
+      if constexpr (RING) {
+        const u32 rel1 = i + 1 - start;               // the same in every lane of the wave
+        if ((rel1 & 15u) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block rel1/16, requested 16 iterations ago
+        e_next = ring_read(rel1);
+        if ((rel1 & 15u) == 0 && rel1 + 16u < pl.L1) ring_fill((rel1 >> 4) + 1u);  // reuse the buffer of the block just finished
+      } else {
+        e_next = sorted[i + 1];
+      }
       const uint4* p = points + (size_t)(e_next & 0xffffffu) * 4;
       F::load(nx, p); F::load(ny, p + 2);
     }

@@ -51,6 +51,8 @@ LEMSM_EXTERN_ACC(GqLazy, 2) LEMSM_EXTERN_ACC(GqLazy, 3) LEMSM_EXTERN_ACC(GqLazy,
 LEMSM_EXTERN_ACC(GrLazy, 2) LEMSM_EXTERN_ACC(GrLazy, 3) LEMSM_EXTERN_ACC(GrLazy, 4)
 extern template __global__ void lemsm::k_accum1<GqLazy, 3, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
 extern template __global__ void lemsm::k_accum1<GrLazy, 3, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+extern template __global__ void lemsm::k_accum1<GqLazy, 3, true, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+extern template __global__ void lemsm::k_accum1<GrLazy, 3, true, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
 extern template __global__ void lemsm::k_convert_points<Field29<Fq29Params>>(const uint4*, uint4*, u32);
 extern template __global__ void lemsm::k_convert_points<Field29<Fr29Params>>(const uint4*, uint4*, u32);
 namespace {
@@ -86,7 +88,8 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0;
+  bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
@@ -322,7 +325,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t o_tinfo = take((size_t)pl.max_tiles * 16 + 16);
   size_t o_sbm = take(pl.c == 17 ? (size_t)(pl.w1 - pl.w0) * ((pl.n + 63) / 64) * 8 + 16 : 16);
   size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
-  size_t o_entries = take(Mmax * 4 + 16), o_sorted = take(Mmax * 4 + 16);
+  size_t o_entries = take(Mmax * 4 + 4 * (size_t)pl.L1 + 512), o_sorted = take(Mmax * 4 + 4 * (size_t)pl.L1 + 512);   // (+ slack: the entry ring stages whole 64-byte blocks)
   size_t R1 = 2 * (size_t)pl.nthr1;
   size_t R2 = 2 * ((R1 + 1) / 2);   // first edge level writes 2 records per `per` >= 2 inputs (option seg_records)
   size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * ptb + 256), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * ptb + 256);
@@ -372,6 +375,9 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
     size_t l = (Mmax + target - 1) / target;
     L1 = (u32)std::max((size_t)8, std::min((size_t)256, l));
   }
+  // the entry ring of k_accum1 stages 16-entry blocks: when that form will run (run_windows sets the flag once it
+  // has chosen the ABI form), chunks are a multiple of 16 entries
+  if (ctx->plan_ring && ctx->opt_chunk == 0 && L1 >= 32) L1 = (L1 + 15u) & ~15u;
   g.L1 = L1;
   g.nthr1 = (u32)((Mmax + L1 - 1) / L1);
   if (g.nthr1 == 0) g.nthr1 = 1;
@@ -495,6 +501,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     if constexpr (G::CONVERTED_DOMAIN) {
       if (wps == 2) hipLaunchKernelGGL((k_accum1<G, 2>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
       else if (wps == 4) hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      else if (abi && (pl.L1 & 15u) == 0 && pl.L1 >= 32 && ctx->opt_entry_ring != 1) hipLaunchKernelGGL((k_accum1<G, 3, true, true>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
       else if (abi) hipLaunchKernelGGL((k_accum1<G, 3, true>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
       else hipLaunchKernelGGL((k_accum1<G, 3>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
     } else {
@@ -628,6 +635,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   // are added on the host.  Device-resident inputs use the largest slab the 32-bit entry format
   // allows; host-pointer entries (ctx->host_stage) use small slabs so that the PCIe upload of slab
   // k+1 (upload queue, host blocked in the copy) overlaps the kernels of slab k (main queue).
+  ctx->plan_ring = false;
   const HostStage* hs = ctx->host_stage;
   u32 slab_log = ctx->opt_slab_bits ? (u32)ctx->opt_slab_bits : MAX_SLAB_LOG;
   if (hs) slab_log = host_slab_log(ctx, n);
@@ -691,6 +699,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     // wave opens a segment).  With S = average segment length the second costs P = 1-(1-1/S)^64 of
     // 110/2058 of the accumulation (68 ps per point and window): cheaper when P * windows < 7.
     bool abi = false;
+    ctx->plan_ring = false;
     if constexpr (G::CONVERTED_DOMAIN) {
       GroupPlan pl0 = make_group_plan(ctx, sn, c, nb, W, groups[0].g0, groups[0].g1, d);
       double S = std::max(1.0, std::min((double)pl0.L1, (double)sn / (double)nb));
@@ -698,6 +707,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
       abi = P * (double)(groups[0].g1 - groups[0].g0) < 7.0 && (ctx->opt_accum_waves == 0 || ctx->opt_accum_waves == 3);
       if (ctx->opt_abi_points == 1) abi = false;
       if (ctx->opt_abi_points == 2) abi = (ctx->opt_accum_waves == 0 || ctx->opt_accum_waves == 3);
+      ctx->plan_ring = abi && ctx->opt_entry_ring != 1;
       if (!abi) {
         hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, s_acc, (const uint4*)pts, (uint4*)d_conv, sn);
         pts = d_conv;
@@ -1092,6 +1102,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
   else if (!strcmp(name, "xcd_windows")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_xcd_windows = value; }
+  else if (!strcmp(name, "entry_ring")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_entry_ring = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
   else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }

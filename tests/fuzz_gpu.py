@@ -62,14 +62,14 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = api.Context(0)
     t0 = time.time(); cases = 0
-    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "seg_records", "accum_waves", "host_slab_bits", "groups"]
+    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "seg_records", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows"]
     while time.time() - t0 < secs:
         curve = CURVES[int(rng.integers(0, 2))]
         opts = {"window_bits": int(rng.choice([0, 0, 2, 3, 5, 8, 11, 13, 16, 17])), "chunk": int(rng.choice([0, 0, 1, 3, 17, 64, 300])),
                 "tile": int(rng.choice([0, 0, 256, 1000])), "field": int(rng.choice([0, 0, 1])), "abi_points": int(rng.integers(0, 3)),
                 "slab_bits": int(rng.choice([0, 0, 12, 14])), "seg_records": int(rng.choice([0, 2, 5, 8, 16])),
                 "accum_waves": int(rng.choice([0, 0, 2, 4])), "host_slab_bits": int(rng.choice([0, 12, 13, 16])),
-                "groups": 0}
+                "groups": 0, "entry_ring": int(rng.integers(0, 2)), "xcd_windows": int(rng.integers(0, 2))}
         host_entry = rng.random() < 0.5
         if not host_entry:
             opts["groups"] = int(rng.choice([0, 0, 2, 3]))     # pipelined window groups: device-pointer entries only

@@ -19,15 +19,16 @@ pytestmark = pytest.mark.gpu
 # (field, abi_points): field 0 = lazy radix-2^29 arithmetic (default hot path), 1 = strict 32-bit limbs;
 # abi_points 1 = points converted by a pass before the accumulation, 2 = accumulation consumes the C ABI's
 # form directly (scaled accumulators); the library picks between the two by size, the tests force each
-VARIANTS = [(0, 1), (0, 2), (1, 0)]
+# entry_ring 1 = every lane loads its entries itself, 0 = through the per-wave LDS ring (only with abi_points form)
+VARIANTS = [(0, 1, 0), (0, 2, 0), (0, 2, 1), (1, 0, 0)]
 
 
-@pytest.fixture(params=VARIANTS, ids=["lazy29-convert-pass", "lazy29-abi-points", "strict32"])
+@pytest.fixture(params=VARIANTS, ids=["lazy29-convert-pass", "lazy29-abi-points-entry-ring", "lazy29-abi-points-no-ring", "strict32"])
 def fctx(ctx, request):
     """context with the arithmetic of the hot kernels selected"""
-    ctx.set_option("field", request.param[0]); ctx.set_option("abi_points", request.param[1])
+    ctx.set_option("field", request.param[0]); ctx.set_option("abi_points", request.param[1]); ctx.set_option("entry_ring", request.param[2])
     yield ctx
-    ctx.set_option("field", 0); ctx.set_option("abi_points", 0)
+    ctx.set_option("field", 0); ctx.set_option("abi_points", 0); ctx.set_option("entry_ring", 0)
 
 
 # ------------------------------------------------------------------ field / group KATs
