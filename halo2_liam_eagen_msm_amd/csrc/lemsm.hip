@@ -654,12 +654,15 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   std::vector<Grp> groups;
   size_t ws_total = 0;
   {
-    u32 sn0 = (u32)std::min(SLAB, n);
+    // a group's workspace must hold the layout of EVERY slab: the ragged last slab can need more of some
+    // buffers than a full one (below 2^16 points the pass-1 ranges shrink, so there are more of them)
+    u32 sn0 = (u32)std::min(SLAB, n), snl = (u32)(n - (nslabs - 1) * SLAB);
     for (u32 g0 = wb; g0 < we; g0 += gsz) {
       u32 g1 = std::min(we, g0 + gsz);
-      GroupPlan pl = make_group_plan(ctx, sn0, c, nb, W, g0, g1, d);
+      size_t bytes = group_ws_bytes(make_group_plan(ctx, sn0, c, nb, W, g0, g1, d), nbp, L, ptb);
+      if (snl != sn0) bytes = std::max(bytes, group_ws_bytes(make_group_plan(ctx, snl, c, nb, W, g0, g1, d), nbp, L, ptb));
       groups.push_back({g0, g1, ws_total});
-      ws_total += align_up(group_ws_bytes(pl, nbp, L, ptb), 256);
+      ws_total += align_up(bytes + 8192, 256);     // (+ slack for the 16-entry rounding of the accumulate chunk, see make_group_plan)
     }
   }
   const size_t ng = groups.size();

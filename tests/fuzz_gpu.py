@@ -77,10 +77,14 @@ def main():
             ctx.set_option(k, opts[k])
         if rng.random() < 0.75:
             n, shape, sc, pts = make_case(rng, curve)
-            got = ctx.msm(curve.cid, sc, pts) if host_entry else None
-            if got is None:
-                ds, dp = ctx.to_device(sc), ctx.to_device(pts)
-                got = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+            try:
+                got = ctx.msm(curve.cid, sc, pts) if host_entry else None
+                if got is None:
+                    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+                    got = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+            except Exception as ex:
+                print("EXCEPTION %r seed=%d case=%d %s n=%d shape=%s host_entry=%s opts=%s" % (ex, seed, cases, curve.name, n, shape, host_entry, opts), flush=True)
+                raise
             exp = cref.best_multiexp(curve.cid, sc, pts, 8)
             what = "msm"
         else:

@@ -296,6 +296,29 @@ def test_msm_device_entry_multi_slab(fctx, groups):
         ctx.set_option("slab_bits", 0); ctx.set_option("groups", 0)
 
 
+@pytest.mark.parametrize("n,opts,host", [(130972, {"slab_bits": 16, "seg_records": 2}, False), (262017, {"host_slab_bits": 16, "seg_records": 2}, True),
+                                         ((1 << 19) + 60000, {}, True)],
+                         ids=["device-2^16-slabs-ragged-last", "host-2^16-slabs-ragged-last", "host-default-slabs-last-slab-below-2^16"])
+def test_msm_ragged_last_slab_workspace(ctx, n, opts, host):
+    """regression (found by tests/fuzz_gpu.py): a last slab of fewer than 2^16 pairs uses shorter pass-1 ranges,
+    hence MORE of them than a full slab of 2^16..2^19 pairs; the workspace is sized over every slab's layout"""
+    curve = pyref.BN254_G1
+    pts = cref.gen_points(curve.cid, 11, 300)[np.random.default_rng(1).integers(0, 300, n)]
+    sc = cref.gen_scalars(curve.cid, 12, n)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    try:
+        if host:
+            got = ctx.msm(curve.cid, sc, pts)
+        else:
+            ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+            got = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+    finally:
+        for k in opts:
+            ctx.set_option(k, 0)
+    assert canon(curve, got) == canon(curve, cref.best_multiexp(curve.cid, sc, pts, 16))
+
+
 def test_msm_host_entry_bad_scalar_in_later_slab(ctx):
     curve = pyref.BN254_G1
     n = 3 * 4096 + 17
