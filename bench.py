@@ -181,21 +181,21 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.workload, curve, logn, world),
                     "kernel": "k_accum1", "kernel_ms": round(accum_ms, 4), "launches_per_step": launches_per_step, "pipeline_device_ms": round(tot_ms / args.steps, 4),
                     "note": "integer-ALU-bound path: 96 algorithmic B/pair vs 8 TB/s HBM; see DESIGN.md for the VALU roofline"}
-        # the bound that actually binds: VALU issue.  One mixed addition = 2072 VALU instructions
-        # (PMC SQ_INSTS_VALU x 64 / additions, profiles/r01/v_pmc_accum1_valu_final.csv); a SIMD issues one wave instruction per 4 cycles at best; the
-        # chip sustains ~1.89 GHz under this load (PMC GRBM_GUI_ACTIVE / duration, profiles/r01).
+        # the bound that actually binds: VALU issue.  One mixed addition = 2083 VALU instructions
+        # (PMC SQ_INSTS_VALU x 64 / additions, profiles/r01/zz_pmc_valu_entry_ring.csv); a SIMD issues one wave instruction per 4 cycles at best; the
+        # chip sustains ~1.90 GHz under this load (PMC GRBM_GUI_ACTIVE / duration, profiles/r01).
         if args.workload == "msm":
             units, nonzero = ctx.msm_plan(curve, n)[0], 1.0
         else:
             units, nonzero = ctx.lhs_plan(curve, args.base)[0], (args.base - 1) / args.base
         madds = n * units * nonzero / world / launches_per_step
-        wave_instr = madds * 2072 / 64
-        valu_peak = 1024 * 1.89e9 / 4
-        roofline["valu_issue"] = {"instr_per_madd": 2072, "madds_per_launch": int(madds),
+        wave_instr = madds * 2083 / 64
+        valu_peak = 1024 * 1.90e9 / 4
+        roofline["valu_issue"] = {"instr_per_madd": 2083, "madds_per_launch": int(madds),
                                   "achieved_Gwaveinstr_s": round(wave_instr / (accum_ms * 1e-3) / 1e9, 1) if accum_ms > 0 else 0.0,
                                   "peak_Gwaveinstr_s": round(valu_peak / 1e9, 1),
                                   "frac": round(wave_instr / (accum_ms * 1e-3) / valu_peak, 4) if accum_ms > 0 else 0.0,
-                                  "clock_ghz_assumed": 1.89}
+                                  "clock_ghz_assumed": 1.90}
         out = {
             "metric": "BN254 G1 MSM scalar-point-pairs/s" if curve == "bn254_g1" else "Grumpkin MSM scalar-point-pairs/s",
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
