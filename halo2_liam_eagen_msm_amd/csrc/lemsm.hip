@@ -377,7 +377,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   }
   // the entry ring of k_accum1 stages 16-entry blocks: when that form will run (run_windows sets the flag once it
   // has chosen the ABI form), chunks are a multiple of 16 entries
-  if (ctx->plan_ring && ctx->opt_chunk == 0 && L1 >= 32) L1 = (L1 + 15u) & ~15u;
+  if (ctx->plan_ring && ctx->opt_chunk == 0 && L1 >= 128) L1 = (L1 + 15u) & ~15u;   // (short chunks: the ring's per-chunk prologue costs more than it saves: profiles/r01/zz_entry_ring_small_sizes.txt)
   g.L1 = L1;
   g.nthr1 = (u32)((Mmax + L1 - 1) / L1);
   if (g.nthr1 == 0) g.nthr1 = 1;
