@@ -1,0 +1,46 @@
+"""bench.py: the driver's contract (one JSON line, the keys and types it reads) and the synthetic
+scalar generator."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_gen_scalars_are_canonical_and_deterministic():
+    import bench
+    for name in ("bn254_g1", "grumpkin"):
+        m = bench.ORDER[name]
+        a = bench.gen_scalars(5000, m, 42); b = bench.gen_scalars(5000, m, 42); c = bench.gen_scalars(5000, m, 43)
+        assert a.shape == (5000, 32) and a.dtype == np.uint8
+        assert np.array_equal(a, b) and not np.array_equal(a, c)
+        vals = [int.from_bytes(r.tobytes(), "little") for r in a]
+        assert max(vals) < m and len(set(vals)) > 4990
+        assert max(vals) > m >> 3          # spread over the whole range, not a narrow band
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--workload", "lhs"]], ids=["msm", "lhs"])
+def test_bench_prints_one_contract_line(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--logn", "12",
+           "--cpu-sample-log", "10"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["value"] > 0 and "workload" in d["config"] and d["config"]["bit_exact"] is True
+    ro = d["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-5 and ro["kernel"] == "k_accum1" and ro["kernel_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and isinstance(cb["sample"], str)
