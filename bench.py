@@ -34,7 +34,8 @@ ORDER = {
     "grumpkin": 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47,
 }
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_GINSTR = 35700.0       # measured lane-instructions/s, profiles/r01_valu_rates_microbench.txt
+VALU_ISSUE_CYCLES = 4            # cycles per wave64 VALU instruction per SIMD with >= 2 waves (profiles/r02/valu_rates_microbench.txt)
+MAX_CLOCK_GHZ = 2.4              # MI355X peak engine clock (MI355X_MICROARCH.md); the VALU-issue peak is priced at it
 BYTES_PER_PAIR = 96              # 32 B scalar + 64 B affine point
 
 
@@ -127,7 +128,7 @@ def main():
     gx, gy = (1, 2) if cid == 0 else (1, 0x2CF135E7506A45D632D270D45F1181294833FC48D823F272C)
     q[:4] = np.frombuffer(((gx << 256) % fp).to_bytes(32, "little"), np.uint64)
     q[4:] = np.frombuffer(((gy << 256) % fp).to_bytes(32, "little"), np.uint64)
-    d_points = ctx.gen_walk(cid, q, n)
+    d_points = ctx.gen_walk(cid, q, n)   # P_i = (i+1) Q: sum s_i P_i == (sum s_i (i+1)) Q, the closed form verify_timed_result checks
     t_in = time.time() - t_in
 
     if world > 1 and args.workload == "msm" and args.sharding == "windows":
@@ -154,11 +155,15 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    acc_ms = 0.0; tot_ms = 0.0; launches = 0
+    acc_ms = 0.0; tot_ms = 0.0; launches = 0; clock_sum = 0.0; clock_n = 0
     for _ in range(args.steps):
         result = step()
         tt, ta, nl = ctx.last_timing()
         acc_ms += ta; tot_ms += tt; launches += nl
+        ck = ctx.last_accum_clock_mhz()
+        if ck > 0:
+            clock_sum += ck; clock_n += 1
+    clock_mhz = clock_sum / clock_n if clock_n else 0.0
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -179,23 +184,32 @@ def main():
         achieved = BYTES_PER_PAIR * n / world / launches_per_step / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.workload, curve, logn, world),
+                    "traffic_source": "committed rocprofv3 PMC passes of this command (profiles/traffic_accum1.json), not measured in this run",
                     "kernel": "k_accum1", "kernel_ms": round(accum_ms, 4), "launches_per_step": launches_per_step, "pipeline_device_ms": round(tot_ms / args.steps, 4),
                     "note": "integer-ALU-bound path: 96 algorithmic B/pair vs 8 TB/s HBM; see DESIGN.md for the VALU roofline"}
-        # the bound that actually binds: VALU issue.  One mixed addition = 2083 VALU instructions
-        # (PMC SQ_INSTS_VALU x 64 / additions, profiles/r01/zz_pmc_valu_entry_ring.csv); a SIMD issues one wave instruction per 4 cycles at best; the
-        # chip sustains ~1.90 GHz under this load (PMC GRBM_GUI_ACTIVE / duration, profiles/r01).
+        # the bound that actually binds: VALU issue.  Peak = 1024 SIMDs x 2.4 GHz (the guide's maximum engine clock) / 4
+        # cycles per wave instruction, so frac <= 1 by construction; the clock the kernel actually sustained is measured
+        # live (in-kernel s_memtime / s_memrealtime stamps, lemsm_last_accum_clock_mhz) and reported beside it.  The
+        # instruction count per mixed addition is model input from the committed PMC pass (profiles/valu_accum1.json).
         if args.workload == "msm":
             units, nonzero = ctx.msm_plan(curve, n)[0], 1.0
         else:
             units, nonzero = ctx.lhs_plan(curve, args.base)[0], (args.base - 1) / args.base
+        vm = valu_model()
         madds = n * units * nonzero / world / launches_per_step
-        wave_instr = madds * 2083 / 64
-        valu_peak = 1024 * 1.90e9 / 4
-        roofline["valu_issue"] = {"instr_per_madd": 2083, "madds_per_launch": int(madds),
-                                  "achieved_Gwaveinstr_s": round(wave_instr / (accum_ms * 1e-3) / 1e9, 1) if accum_ms > 0 else 0.0,
-                                  "peak_Gwaveinstr_s": round(valu_peak / 1e9, 1),
-                                  "frac": round(wave_instr / (accum_ms * 1e-3) / valu_peak, 4) if accum_ms > 0 else 0.0,
-                                  "clock_ghz_assumed": 1.90}
+        wave_instr = madds * vm["instr_per_madd"] / 64
+        valu_peak = 1024 * MAX_CLOCK_GHZ * 1e9 / VALU_ISSUE_CYCLES
+        ach = wave_instr / (accum_ms * 1e-3) if accum_ms > 0 else 0.0
+        clk = clock_mhz / 1e3
+        roofline["valu_issue"] = {"instr_per_madd": vm["instr_per_madd"], "instr_per_madd_source": vm["source"],
+                                  "madds_per_launch": int(madds),
+                                  "achieved_Gwaveinstr_s": round(ach / 1e9, 1), "peak_Gwaveinstr_s": round(valu_peak / 1e9, 1),
+                                  "frac": round(ach / valu_peak, 4), "peak_clock_ghz": MAX_CLOCK_GHZ,
+                                  "clock_ghz_measured": round(clk, 3) if clk > 0 else None,
+                                  "cycles_per_wave_instr_per_simd_at_measured_clock": round(1024 * clk * 1e9 / ach, 3) if (clk > 0 and ach > 0) else None,
+                                  "model": "model-derived: PMC instruction count x launches / HIP-event time"}
+        # ---- the timed result itself (last timed step) against the closed form of the synthetic input ----
+        checks = verify_timed_result(cid, curve, scalars, q, result, args)
         out = {
             "metric": "BN254 G1 MSM scalar-point-pairs/s" if curve == "bn254_g1" else "Grumpkin MSM scalar-point-pairs/s",
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,12 +217,17 @@ def main():
             "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
             "config": {"workload": ("%s MSM, 2^%d points, full-width scalars" % (curve, logn)) if args.workload == "msm"
                        else ("%s compute_lhs_witness MSM core, 2^%d points, negabase B=%d (w=4), half-width scalars" % (curve, logn, args.base)),
-                       "n": n, "curve": curve, "sharding": ("pairs x%d" if (args.sharding == "points" and args.workload == "msm") else "pippenger-window x%d") % world, "bit_exact": True,
+                       "n": n, "curve": curve, "sharding": ("pairs x%d" if (args.sharding == "points" and args.workload == "msm") else "pippenger-window x%d") % world,
+                       "baseline_config": baseline_config(args.workload, curve, logn, world, args.base),
                        "input_gen_s": round(t_in, 2)},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args, world)
+            checks.append("sample vs oracle")
+        # bit_exact is derived from checks that ran in THIS process (each raises on a mismatch); null when none did
+        out["config"]["bit_exact"] = True if checks else None
+        out["config"]["bit_exact_checks"] = checks
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -230,26 +249,79 @@ def pmc_traffic(workload, curve, logn, world):
     return None if ent is None else ent["bytes_per_launch"]
 
 
-def cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args):
-    """Oracle leg (checker + timed CPU baseline, rank 0, N = 1 only): the C restatement of halo2
-    best_multiexp (thread-chunked serial Pippenger) on a bounded sample of the same inputs, all host
-    threads; the GPU result on the same sample must match bit-exactly."""
+def valu_model():
+    """VALU wave-instructions per mixed addition of k_accum1, from the committed PMC pass (SQ_INSTS_VALU)."""
+    path = os.path.join(ROOT, "profiles", "valu_accum1.json")
+    try:
+        ent = json.load(open(path))["msm/bn254_g1/2^24/x1"]
+        return {"instr_per_madd": ent["instr_per_madd"], "source": "profiles/valu_accum1.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+    except Exception:
+        return {"instr_per_madd": 2083, "source": "constant (profiles/valu_accum1.json unreadable)"}
+
+
+def baseline_config(workload, curve, logn, world, base):
+    """which BASELINE.json config this run is, if any"""
+    if workload == "lhs" and curve == "bn254_g1" and logn == 20 and base == 16 and world == 1:
+        return "configs[1]"
+    if workload == "msm" and curve == "bn254_g1" and logn == 24:
+        return "configs[2]" if world == 1 else "configs[2] sharded x%d (north_star: 2^24 at 1/2/4/8 GPUs)" % world
+    if workload == "msm" and curve == "bn254_g1" and logn == 26 and world == 8:
+        return "configs[3]"
+    if workload == "msm" and curve == "grumpkin" and logn == 22 and world == 1:
+        return "configs[4]"
+    return None
+
+
+def verify_timed_result(cid, curve, scalars, q, result, args):
+    """Checker leg (oracle as the checker only): the result of the LAST TIMED step must equal (sum_i s_i (i+1)) Q,
+    the closed form of the synthetic input P_i = (i+1) Q -- one host dot product mod the group order and one
+    scalar multiplication.  Raises on a mismatch; returns the list of checks that passed."""
     from oracle import cref
-    cores = os.cpu_count() or 1
-    slog = args.cpu_sample_log if args.cpu_sample_log is not None else min(logn, 21)
+    exp = cref.jac_to_canonical(cid, cref.scalar_mul(cid, cref.walk_dot(cid, scalars), q))
+    got = cref.jac_to_canonical(cid, np.ascontiguousarray(result, np.uint64))
+    if got != exp:
+        raise SystemExit("the timed %s result differs from the closed form of the synthetic input: parity broken" % args.workload)
+    return ["timed result vs walk identity"]
+
+
+def cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args, world):
+    """Oracle leg (checker + timed CPU baseline, rank 0 only): a bounded sample of the same inputs through the
+    oracle's restatement of the reference's CPU path for THIS workload, and the GPU result on that sample
+    compared bit-exactly (single-GPU entry, whatever N is).
+      msm: halo2 best_multiexp (thread-chunked serial Pippenger), all host threads;
+      lhs: compute_lhs_witness' MSM core, serial like the reference (src/argument_witness_calc.rs:99-127 has no
+           parallel loop), one thread."""
+    from oracle import cref
+    if args.workload == "msm":
+        cores = os.cpu_count() or 1
+        slog = args.cpu_sample_log if args.cpu_sample_log is not None else min(logn, 21 if world == 1 else 19)
+    else:
+        cores = 1
+        slog = args.cpu_sample_log if args.cpu_sample_log is not None else min(logn, 18 if world == 1 else 16)
     m = 1 << slog
     pts = d_points.download(np.uint64, m * 64).reshape(-1, 8)
     sc = np.ascontiguousarray(scalars[:m])
-    t0 = time.perf_counter()
-    ref = cref.best_multiexp(cid, sc, pts, cores)
-    dt = time.perf_counter() - t0
     ds = ctx.to_device(sc)
-    got = ctx.msm_device(cid, ds.ptr, d_points.ptr, m)
-    ok = cref.jac_to_canonical(cid, got) == cref.jac_to_canonical(cid, ref)
+    if args.workload == "msm":
+        t0 = time.perf_counter()
+        ref = cref.best_multiexp(cid, sc, pts, cores)
+        dt = time.perf_counter() - t0
+        got = ctx.msm_device(cid, ds.ptr, d_points.ptr, m)
+        ok = cref.jac_to_canonical(cid, got) == cref.jac_to_canonical(cid, ref)
+        what = "best_multiexp restatement (oracle/c)"
+    else:
+        jac = cref.aff_to_jac(cid, pts)
+        t0 = time.perf_counter()
+        ref, refs = cref.lhs_msm(cid, sc, jac, args.base, True)
+        dt = time.perf_counter() - t0
+        got, gots = ctx.lhs_msm_device(cid, ds.ptr, d_points.ptr, m, args.base, True)
+        ok = cref.jac_to_canonical(cid, got) == cref.jac_to_canonical(cid, ref) and all(
+            cref.jac_to_canonical(cid, gots[i]) == cref.jac_to_canonical(cid, refs[i]) for i in range(refs.shape[0]))
+        what = "compute_lhs_witness MSM core restatement (oracle/c, serial like the reference), all %d per-digit carries compared" % refs.shape[0]
     if not ok:
         raise SystemExit("GPU result differs from the CPU oracle on the sample: parity broken")
     return {"value": round(m / dt, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "first 2^%d pairs of the same inputs, best_multiexp restatement (oracle/c), %.2f s, GPU result on the sample bit-exact" % (slog, dt)}
+            "sample": "first 2^%d pairs of the same inputs, %s, %.2f s, GPU result on the sample bit-exact" % (slog, what, dt)}
 
 
 if __name__ == "__main__":

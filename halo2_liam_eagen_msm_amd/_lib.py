@@ -29,8 +29,8 @@ GRUMPKIN = 1
 # Every symbol include/lemsm.h declares (tests/test_abi.py checks the header against this list
 # and that the built library exports each of them).
 SYMBOLS = [
-    "lemsm_create", "lemsm_destroy", "lemsm_strerror", "lemsm_last_error", "lemsm_last_bad_index", "lemsm_set_option",
-    "lemsm_last_timing",
+    "lemsm_create", "lemsm_destroy", "lemsm_strerror", "lemsm_last_error", "lemsm_last_bad_index", "lemsm_last_truncated_count", "lemsm_set_option",
+    "lemsm_last_timing", "lemsm_last_accum_clock_mhz",
     "lemsm_msm", "lemsm_msm_bn254_g1", "lemsm_msm_grumpkin", "lemsm_msm_device",
     "lemsm_msm_plan", "lemsm_msm_partial_device", "lemsm_msm_combine",
     "lemsm_num_digits", "lemsm_negbase_decompose_batch",
@@ -77,8 +77,10 @@ def load() -> ctypes.CDLL:
         "lemsm_strerror": (ctypes.c_char_p, [i]),
         "lemsm_last_error": (ctypes.c_char_p, [vp]),
         "lemsm_last_bad_index": (ctypes.c_size_t, [vp]),
+        "lemsm_last_truncated_count": (ctypes.c_size_t, [vp]),
         "lemsm_set_option": (i, [vp, ctypes.c_char_p, ctypes.c_long]),
         "lemsm_last_timing": (i, [vp, ctypes.POINTER(ctypes.c_double)]),
+        "lemsm_last_accum_clock_mhz": (i, [vp, ctypes.POINTER(ctypes.c_double)]),
         "lemsm_msm": (i, [vp, i, u8p, u64p, sz, u64p]),
         "lemsm_msm_bn254_g1": (i, [vp, u8p, u64p, sz, u64p]),
         "lemsm_msm_grumpkin": (i, [vp, u8p, u64p, sz, u64p]),

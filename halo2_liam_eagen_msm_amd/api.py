@@ -161,6 +161,17 @@ class Context:
         self._check(self.lib.lemsm_last_timing(self.h, out))
         return out[0], out[1], int(out[2])
 
+    def last_accum_clock_mhz(self) -> float:
+        """shader clock (MHz) the accumulate kernel of the last MSM call sustained (in-kernel stamps)"""
+        out = ctypes.c_double()
+        self._check(self.lib.lemsm_last_accum_clock_mhz(self.h, ctypes.byref(out)))
+        return out.value
+
+    def last_truncated_count(self) -> int:
+        """scalars of the last negabase pass whose expansion did not fit d digits (silently
+        truncated like the reference's `.take(d)`, src/argument_witness_calc.rs:99)"""
+        return int(self.lib.lemsm_last_truncated_count(self.h))
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 

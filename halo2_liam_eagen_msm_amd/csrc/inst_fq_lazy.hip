@@ -3,11 +3,11 @@
 #include "kernels_ec.cuh"
 using namespace lemsm;
 typedef XYZZ29<Field29<Fq29Params>> G;
-template __global__ void lemsm::k_accum1<G, 2>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
-template __global__ void lemsm::k_accum1<G, 3>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
-template __global__ void lemsm::k_accum1<G, 3, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
-template __global__ void lemsm::k_accum1<G, 3, true, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
-template __global__ void lemsm::k_accum1<G, 4>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+template __global__ void lemsm::k_accum1<G, 2>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
+template __global__ void lemsm::k_accum1<G, 3>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
+template __global__ void lemsm::k_accum1<G, 3, true>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
+template __global__ void lemsm::k_accum1<G, 3, true, true>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
+template __global__ void lemsm::k_accum1<G, 4>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
 template __global__ void lemsm::k_segreduce<G>(u32, u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);

@@ -3,7 +3,7 @@
 #include "kernels_ec.cuh"
 using namespace lemsm;
 typedef XYZZ<Field32<FqParams>> G;
-template __global__ void lemsm::k_accum1<G, 4>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+template __global__ void lemsm::k_accum1<G, 4>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
 template __global__ void lemsm::k_segreduce<G>(u32, u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);

@@ -143,9 +143,9 @@ struct PipDec {
 // negabase digit matrix, position-major; bucket id = digit (id_by_digit: digit-1, 0 skipped;
 // src/negbase_utils.rs:46-51)
 struct NegDec {
-  const uint8_t* digitsT;   // d x n
+  const uint8_t* digitsT;   // d x nstride, already offset to this slab's first column
   __device__ __forceinline__ void get(u32 j, u32 w, const GroupPlan& pl, u32& bucket, u32& sign) const {
-    bucket = digitsT[(size_t)w * pl.n + j]; sign = 0;
+    bucket = digitsT[(size_t)w * pl.nstride + j]; sign = 0;
   }
 };
 

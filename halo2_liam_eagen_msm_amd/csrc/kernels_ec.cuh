@@ -11,7 +11,7 @@ namespace lemsm {
 static const u32 KEY_NONE = 0xffffffffu;
 
 // meta words written by k_binscan
-enum { META_M = 0, META_TILES = 1, META_WORDS = 4 };
+enum { META_M = 0, META_TILES = 1, META_WORDS = 4, META_CLOCK = 8 /* 4 x u64 written by k_accum1: (shader cycles, 100 MHz ticks) at the start and at the end of one wave's chunk */ };
 
 // ------------------------------------------------------------------------------------
 // level 1: segmented accumulation of the bucket-sorted entry list.
@@ -23,7 +23,7 @@ template <class G, int WPS /* waves per SIMD the register budget is sized for */
           bool ABI = false /* points in the C ABI's domain, accumulator and outputs in the scaled form: G::madd_abi */,
           bool RING = false /* entries reach the lanes through a per-wave LDS ring filled by global_load_lds (needs L1 % 16 == 0) */>
 __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __restrict__ sorted,
-                                                const u32* __restrict__ bucket_start, const u32* __restrict__ meta,
+                                                const u32* __restrict__ bucket_start, u32* __restrict__ meta,
                                                 const uint4* __restrict__ points, char* __restrict__ bucket_sum,
                                                 u32* __restrict__ rec_key, char* __restrict__ rec_pt) {
   typedef typename G::F_ F;
@@ -31,6 +31,15 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   if (t >= pl.nthr1) return;
   const u32 M = meta[META_M];
+  // Sustained shader clock of THIS launch (bench.py's roofline.valu_issue.clock_ghz_measured): one wave in the
+  // middle of the grid stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its whole chunk;
+  // clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, in-kernel clock).  Two scalar reads per launch.
+  // (The opening stamps go straight to memory: held in registers across the loop they cost 4 more spilled VGPRs.)
+  const bool stamp = blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0;
+  if (stamp) {
+    u64* ck = reinterpret_cast<u64*>(meta + META_CLOCK);
+    ck[0] = __builtin_amdgcn_s_memtime(); ck[1] = __builtin_amdgcn_s_memrealtime();
+  }
   const u64 s64 = (u64)t * pl.L1;
   const u32 r0 = 2 * t;
   if (s64 >= M) { rec_key[r0] = KEY_NONE; rec_key[r0 + 1] = KEY_NONE; return; }
@@ -120,6 +129,10 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
     }
   }
   flush(end);
+  if (stamp) {
+    u64* ck = reinterpret_cast<u64*>(meta + META_CLOCK);
+    ck[2] = __builtin_amdgcn_s_memtime(); ck[3] = __builtin_amdgcn_s_memrealtime();
+  }
   // Filler rule (DESIGN.md "edge records"): a lone record is followed by an identity record of
   // the same key, so that a bucket's run of records stays contiguous across threads (KEY_NONE is
   // only ever written where no run can pass through).

@@ -44,15 +44,15 @@ const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUN
   extern template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);                     \
   extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
 #define LEMSM_EXTERN_ACC(G, W) \
-  extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+  extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
 LEMSM_EXTERN_G(GqStrict) LEMSM_EXTERN_G(GrStrict) LEMSM_EXTERN_G(GqLazy) LEMSM_EXTERN_G(GrLazy)
 LEMSM_EXTERN_ACC(GqStrict, 4) LEMSM_EXTERN_ACC(GrStrict, 4)
 LEMSM_EXTERN_ACC(GqLazy, 2) LEMSM_EXTERN_ACC(GqLazy, 3) LEMSM_EXTERN_ACC(GqLazy, 4)
 LEMSM_EXTERN_ACC(GrLazy, 2) LEMSM_EXTERN_ACC(GrLazy, 3) LEMSM_EXTERN_ACC(GrLazy, 4)
-extern template __global__ void lemsm::k_accum1<GqLazy, 3, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
-extern template __global__ void lemsm::k_accum1<GrLazy, 3, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
-extern template __global__ void lemsm::k_accum1<GqLazy, 3, true, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
-extern template __global__ void lemsm::k_accum1<GrLazy, 3, true, true>(GroupPlan, const u32*, const u32*, const u32*, const uint4*, char*, u32*, char*);
+extern template __global__ void lemsm::k_accum1<GqLazy, 3, true>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
+extern template __global__ void lemsm::k_accum1<GrLazy, 3, true>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
+extern template __global__ void lemsm::k_accum1<GqLazy, 3, true, true>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
+extern template __global__ void lemsm::k_accum1<GrLazy, 3, true, true>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
 extern template __global__ void lemsm::k_convert_points<Field29<Fq29Params>>(const uint4*, uint4*, u32);
 extern template __global__ void lemsm::k_convert_points<Field29<Fr29Params>>(const uint4*, uint4*, u32);
 namespace {
@@ -93,7 +93,9 @@ struct lemsm_ctx {
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
+  double accum_clock_mhz = 0;                     // shader clock the accumulate kernel of the last call sustained (in-kernel stamps)
   size_t bad_index = 0;
+  size_t truncated = 0;                          // scalars of the last negabase pass whose expansion needed more than d digits
   std::map<std::vector<u32>, PyrCacheEntry> pyr_cache;   // keyed by (NBpad, nb, nbw, nbp, L, gw)
 };
 
@@ -346,7 +348,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
 
 GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32 w0, u32 w1, u32 d) {
   GroupPlan g; memset(&g, 0, sizeof g);
-  g.n = n; g.c = c; g.nb = nb; g.W = W; g.w0 = w0; g.w1 = w1; g.d = d;
+  g.n = n; g.c = c; g.nb = nb; g.W = W; g.w0 = w0; g.w1 = w1; g.d = d; g.nstride = n;   // run_windows sets nstride to the call's n
   u32 LB = 0;
   while (((nb + (1u << LB) - 1) >> LB) > 256 && LB < MAX_LB) LB++;   // <= 256 coarse bins per window (512 at nb = 2^16)
   g.LB = LB;
@@ -667,7 +669,8 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   }
   const size_t ng = groups.size();
   const size_t out_slab = align_up((size_t)nw * (L + 1) * ptb, 256);   // one slab's records
-  const size_t err_bytes = align_up(nslabs * ng * 8, 256);
+  const size_t ERR_SLOT = 64;   // per (slab, group): err[2] of the digit pass, then k_accum1's clock stamps (4 x u64) at byte 16
+  const size_t err_bytes = align_up(nslabs * ng * ERR_SLOT, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
   int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nslabs + err_bytes + 4096);
   if (rc) return rc;
@@ -719,13 +722,18 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     for (size_t gi = 0; gi < ng; gi++) {
       const Grp& gr = groups[gi];
       GroupPlan pl = make_group_plan(ctx, sn, c, nb, W, gr.g0, gr.g1, d);
+      pl.nstride = (u32)n;   // negabase digit matrix: d rows of n columns, whatever the slab (lhs_partial_t bounds n < 2^32)
       auto src = make_src(s0, sn);
       hipEvent_t* ev = ctx->evpool.data() + 3 * (k * ng + gi);
       rc = run_group<G>(ctx, src, pl, nbp, L, pts, abi, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
                         s_sort, s_acc, s_tail, ev[0], ev[1], ev[2]);
       if (rc) return rc;
       // the group's non-canonical-scalar flag (first 8 bytes of its workspace) survives the workspace reuse
-      HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * 8, ws_base + gr.off, 8, hipMemcpyDeviceToDevice, s_tail));
+      HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT, ws_base + gr.off, 8, hipMemcpyDeviceToDevice, s_tail));
+      {
+        GroupWs gw_ = carve(ws_base + gr.off, pl, make_arena(pl.nbins << pl.LB, nbp, gr.g1 - gr.g0, L), 0, ptb);
+        HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT + 16, gw_.meta + META_CLOCK, 32, hipMemcpyDeviceToDevice, s_tail));
+      }
     }
     if (!one_queue) {   // three queues share one workspace: drain before the next slab reuses it
       HIPCHK(ctx, hipStreamSynchronize(s_sort));
@@ -735,7 +743,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     // one queue: the slabs' kernels are stream-ordered, so the workspace is reused without a drain
   }
   std::vector<char> raw(out_slab * nslabs);
-  std::vector<u32> errw(nslabs * ng * 2);
+  std::vector<u32> errw(nslabs * ng * (ERR_SLOT / 4));
   HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, s_tail));
   HIPCHK(ctx, hipMemcpyAsync(errw.data(), d_err, errw.size() * 4, hipMemcpyDeviceToHost, s_tail));
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s_tail));
@@ -744,16 +752,20 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   ctx->t_total_ms = ms;
   for (size_t k = 0; k < nslabs; k++)   // non-canonical scalars (>= field order) are rejected, never bucketed
     for (size_t gi = 0; gi < ng; gi++) {
-      const u32* ew = errw.data() + (k * ng + gi) * 2;
+      const u32* ew = errw.data() + (k * ng + gi) * (ERR_SLOT / 4);
       if (ew[0]) {
         ctx->bad_index = k * SLAB + (size_t)(~ew[1]);
         return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
       }
     }
+  u64 clk_cyc = 0, clk_ticks = 0;
   for (size_t i = 0; i < nslabs * ng; i++) {
     float a = 0; HIPCHK(ctx, hipEventElapsedTime(&a, ctx->evpool[3 * i + 1], ctx->evpool[3 * i + 2]));
     ctx->t_accum_ms += a; ctx->n_accum++;
+    u64 ck[4]; memcpy(ck, errw.data() + i * (ERR_SLOT / 4) + 4, 32);
+    if (ck[2] > ck[0] && ck[3] > ck[1] && ck[2] - ck[0] < ((u64)1 << 40)) { clk_cyc += ck[2] - ck[0]; clk_ticks += ck[3] - ck[1]; }
   }
+  ctx->accum_clock_mhz = clk_ticks ? (double)clk_cyc / (double)clk_ticks * 100.0 : 0.0;
   std::vector<host::pt> tmp;
   std::vector<char> one((size_t)nw * (L + 1) * ptb);
   for (size_t k = 0; k < nslabs; k++) {
@@ -883,9 +895,6 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   if (rc) return rc;
   // the digit matrix is position-major over the whole n; slabs index it with an offset
   auto make_src = [&](size_t s0, u32) { NegProvider s; s.digitsT = dg.digitsT + s0; return s; };
-  // NegDec indexes digitsT[w * pl.n + j] with pl.n = slab size, so multi-slab inputs need the
-  // full row stride: restrict the lhs path to one slab (n <= 2^24) for now.
-  if (n > ((size_t)1 << MAX_SLAB_LOG)) return fail(ctx, LEMSM_ERR_BAD_ARG, "lhs path supports n <= 2^24 per call");
   std::vector<host::pt> recs;
   rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, recs);
   if (rc) return rc;
@@ -896,6 +905,7 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
     HIPCHK(ctx, hipMemcpyAsync(err, dg.err, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
+  ctx->truncated = err[1];
   if (err[0] != 0xffffffffu) {
     if (bad_index) *bad_index = err[0];
     return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar out of range (>= isqrt(order)+2)");
@@ -1115,10 +1125,17 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
 }
 
 size_t lemsm_last_bad_index(const lemsm_ctx* ctx) { return ctx ? ctx->bad_index : 0; }
+size_t lemsm_last_truncated_count(const lemsm_ctx* ctx) { return ctx ? ctx->truncated : 0; }
 
 int lemsm_last_timing(const lemsm_ctx* ctx, double out[3]) {
   if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
   out[0] = ctx->t_total_ms; out[1] = ctx->t_accum_ms; out[2] = ctx->n_accum;
+  return LEMSM_OK;
+}
+
+int lemsm_last_accum_clock_mhz(const lemsm_ctx* ctx, double* out) {
+  if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
+  *out = ctx->accum_clock_mhz;
   return LEMSM_OK;
 }
 
@@ -1132,13 +1149,13 @@ int lemsm_msm_plan(const lemsm_ctx* ctx, int curve, size_t n, uint32_t* num_wind
 
 int lemsm_msm_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n,
                              uint32_t win_begin, uint32_t win_end, uint8_t* out_partials) {
-  if (!ctx || !out_partials) return LEMSM_ERR_BAD_ARG;
+  if (!ctx || (!out_partials && win_begin != win_end)) return LEMSM_ERR_BAD_ARG;   // an empty range (a rank beyond the last window) writes nothing
   int rc = check_curve(ctx, curve); if (rc) return rc;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::vector<host::pt> out;
   rc = msm_partial_dispatch(ctx, curve, d_scalars, d_points, n, win_begin, win_end, out);
   if (rc) return rc;
-  memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
+  if (!out.empty()) memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
   return LEMSM_OK;
 }
 
@@ -1210,7 +1227,10 @@ int lemsm_negbase_decompose_batch(lemsm_ctx* ctx, const uint8_t* scalars, size_t
                      (u32)base, d, (const u32*)(b + dig_bytes), 0, (uint8_t*)b, (uint8_t*)nullptr, (u32*)(b + dig_bytes) + 8);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(digits, b, (size_t)n * d, hipMemcpyDeviceToHost, ctx->stream));
+  u32 errw[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(errw, (u32*)(b + dig_bytes) + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->truncated = errw[1];
   return LEMSM_OK;
 }
 
@@ -1224,14 +1244,14 @@ int lemsm_lhs_plan(int curve, uint8_t base, uint32_t* num_positions, size_t* par
 
 int lemsm_lhs_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, uint8_t base,
                              uint32_t pos_begin, uint32_t pos_end, uint8_t* out_partials, size_t* bad_index) {
-  if (!ctx || !out_partials) return LEMSM_ERR_BAD_ARG;
+  if (!ctx || (!out_partials && pos_begin != pos_end)) return LEMSM_ERR_BAD_ARG;
   int rc = check_curve(ctx, curve); if (rc) return rc;
   LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::vector<host::pt> out;
   rc = lhs_partial_dispatch(ctx, curve, d_scalars, d_points, n, lp, pos_begin, pos_end, out, bad_index);
   if (rc) return rc;
-  memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
+  if (!out.empty()) memcpy(out_partials, out.data(), out.size() * sizeof(host::pt));
   return LEMSM_OK;
 }
 

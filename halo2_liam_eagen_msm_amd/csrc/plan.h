@@ -31,7 +31,8 @@ struct GroupPlan {
   uint32_t max_tiles;// upper bound on pass-2 tiles
   uint32_t L1;       // entries per thread in the accumulate kernel
   uint32_t nthr1;    // upper bound on accumulate threads = ceil(n*(w1-w0) / L1)
-  uint32_t d;        // negabase: digits per scalar (row stride of the digit matrix)
+  uint32_t d;        // negabase: digits per scalar (number of rows of the position-major digit matrix)
+  uint32_t nstride;  // negabase: row stride of the digit matrix = points of the WHOLE call (a slab sees a column range of it)
 };
 
 }  // namespace lemsm

@@ -73,6 +73,12 @@ const char* lemsm_last_error(const lemsm_ctx* ctx);
 /* index of the offending scalar after a LEMSM_ERR_SCALAR_OUT_OF_RANGE from an entry that has no
    bad_index parameter (lemsm_msm*: a scalar that is not a canonical field element) */
 size_t lemsm_last_bad_index(const lemsm_ctx* ctx);
+/* Number of scalars of the last negabase pass (lemsm_negbase_decompose_batch, lemsm_lhs_*) whose
+   expansion needed more than d digits and was truncated exactly like the reference's
+   `.chain(repeat(0)).take(d)` (src/argument_witness_calc.rs:99).  In-range scalars never truncate for
+   base >= 3 with d = lemsm_num_digits; a non-zero count after a call with a smaller d
+   means the digits no longer recompose the scalar. */
+size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
 /* Tuning / test knobs: "window_bits" (0 = auto), "chunk" (entries per accumulate thread,
    0 = auto), "tile" (pass-2 tile entries, 0 = auto), "field" (0 = lazy radix-2^29 arithmetic, the default;
    1 = strict 32-bit-limb arithmetic, kept for A/B and as an in-library cross-check),
@@ -89,6 +95,9 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value);
 /* Device-time (ms, from HIP events on the context's stream) of the last MSM call: whole
    pipeline in [0], the dominant accumulate kernel in [1], its launch count in [2]. */
 int lemsm_last_timing(const lemsm_ctx* ctx, double out[3]);
+/* Shader clock (MHz) the accumulate kernel of the last MSM call sustained, from in-kernel stamps
+   (s_memtime / s_memrealtime around one mid-grid wave's whole chunk); 0 if no launch stamped. */
+int lemsm_last_accum_clock_mhz(const lemsm_ctx* ctx, double* out);
 
 /* ---- best_multiexp ------------------------------------------------------------------- */
 /* sum_i scalars[i] * points[i]; host buffers. */

@@ -42,5 +42,13 @@ def test_bench_prints_one_contract_line(extra):
     ro = d["roofline"]
     assert ro["bound"] in ("hbm", "mfma") and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-5 and ro["kernel"] == "k_accum1" and ro["kernel_ms"] > 0
+    vi = ro["valu_issue"]
+    assert 0 < vi["frac"] <= 1.0 and vi["peak_clock_ghz"] == 2.4          # priced at the guide's maximum clock: <= 1 by construction
+    assert vi["clock_ghz_measured"] is None or 0.5 < vi["clock_ghz_measured"] <= 2.5
+    assert "timed result vs walk identity" in d["config"]["bit_exact_checks"] and "sample vs oracle" in d["config"]["bit_exact_checks"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and isinstance(cb["sample"], str)
+    # the CPU leg follows the workload: the lhs line times the serial compute_lhs_witness restatement, not best_multiexp
+    assert ("compute_lhs_witness" in cb["sample"]) == (extra != [])
+    if extra:
+        assert cb["cores"] == 1

@@ -36,6 +36,14 @@ def _worker(rank, world, port, kind, q):
             allrec = ldist.all_gather_records(local, W, rec, world, rank)
             out = hostref.msm_combine(curve, n, allrec.tobytes())
             ok = cref.jac_to_canonical(curve.cid, out) == curve.canonical(curve.msm_naive(sc, pts))
+        elif kind == "empty-range":
+            # world > number of windows: the last rank owns nothing and still takes part in the all-gather
+            W, rec = 2, 128
+            w0, w1 = ldist.window_range(W, world, rank)
+            local = np.full((w1 - w0) * rec, 17 + w0, np.uint8)
+            allrec = ldist.all_gather_records(local, W, rec, world, rank)
+            exp = np.concatenate([np.full(rec, 17 + w, np.uint8) for w in range(W)])
+            ok = np.array_equal(allrec, exp)
         elif kind == "points":
             # the alternative partition: pairs split across ranks, one Jacobian partial per rank
             # (oracle-built, arbitrary Z), ONE all-gather, product-library host sum on every rank
@@ -63,8 +71,7 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("kind", ["msm", "lhs", "points"])
+@pytest.mark.parametrize("world,kind", [(2, "msm"), (3, "msm"), (2, "lhs"), (3, "lhs"), (2, "points"), (3, "points"), (3, "empty-range")])
 def test_window_sharded_combine_gloo(world, kind):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

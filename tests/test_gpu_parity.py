@@ -611,3 +611,127 @@ def test_msm_walk_relation_large(ctx, curve, logn):
         ssum = np.frombuffer(b"".join(((x + y) % curve.order).to_bytes(32, "little") for x, y in zip(a, b)), np.uint8).reshape(-1, 32)
         o2 = ctx.msm(curve.cid, sc2, pts); o3 = ctx.msm(curve.cid, ssum, pts)
         assert canon(curve, cref.jac_add(curve.cid, out, o2)) == canon(curve, o3)
+
+
+# ------------------------------------------------------------------ BASELINE.json configs at full size
+def _walk_carries_expected(curve, digs, d, base, q):
+    """scalars c_i of the reference's carry recursion (src/argument_witness_calc.rs:118-125) when P_j = (j+1) Q:
+    c_i = -B c_{i-1} + sum_j digit_{j,i} (j+1)  (digits MSB first), so that carry_i == c_i Q"""
+    n = digs.shape[0]
+    idx = np.arange(1, n + 1, dtype=np.int64)
+    c = 0
+    out = []
+    for i in range(d):
+        t = int((digs[:, d - 1 - i].astype(np.int64) * idx).sum())      # digit < 256, j+1 < 2^26: fits int64
+        c = (-base * c + t) % curve.order
+        out.append(c)
+    return out
+
+
+def test_lhs_bn254_2p20_base16_full_size(ctx):
+    """BASELINE.json configs[1] at full size: 2^20-point BN254 G1 compute_lhs_witness MSM core, negabase B = 16
+    (w = 4), half-width scalars.  Every one of the d = 33 per-digit carries (src/argument_witness_calc.rs:127)
+    is checked through the walk identity carry_i == c_i Q."""
+    curve = pyref.BN254_G1
+    n, base = 1 << 20, 16
+    q = cref.gen_points(curve.cid, 511, 1)[0]
+    dp = ctx.gen_walk(curve.cid, q, n)
+    sc = cref.gen_scalars(curve.cid, 512, n, half=True)
+    ds = ctx.to_device(sc)
+    carry, carries = ctx.lhs_msm_device(curve.cid, ds.ptr, dp.ptr, n, base)
+    assert ctx.last_truncated_count() == 0
+    exp = canon(curve, cref.scalar_mul(curve.cid, cref.walk_dot(curve.cid, sc), q))
+    assert canon(curve, carry) == exp and canon(curve, carries[-1]) == exp
+    d = api.num_digits(curve.cid, base)
+    assert d == 33 and carries.shape[0] == d
+    digs = ctx.negbase_decompose_batch(sc, base, d)
+    for i, c in enumerate(_walk_carries_expected(curve, digs, d, base, q)):
+        assert canon(curve, carries[i]) == canon(curve, cref.scalar_mul(curve.cid, c, q)), i
+
+
+def test_msm_bn254_2p26_window_sharded_x8(ctx):
+    """BASELINE.json configs[3]'s workload on one GPU: 2^26-point BN254 G1 MSM (4 slabs of 2^24), 16-bit windows,
+    the eight window ranges an 8-GPU run hands to its ranks computed one after the other with
+    lemsm_msm_partial_device, then lemsm_msm_combine; checked by the walk identity."""
+    from halo2_liam_eagen_msm_amd import dist as ldist
+    curve = pyref.BN254_G1
+    n = 1 << 26
+    q = cref.gen_points(curve.cid, 611, 1)[0]
+    dp = ctx.gen_walk(curve.cid, q, n)
+    sc = cref.gen_scalars(curve.cid, 612, n)
+    ds = ctx.to_device(sc)
+    exp = canon(curve, cref.scalar_mul(curve.cid, cref.walk_dot(curve.cid, sc), q))
+    del sc
+    ctx.set_option("window_bits", 16)
+    try:
+        W, rec = ctx.msm_plan(curve.cid, n)
+        assert W == 16
+        parts = [ctx.msm_partial_device(curve.cid, ds.ptr, dp.ptr, n, *ldist.window_range(W, 8, r)) for r in range(8)]
+        allp = np.concatenate(parts)
+        assert allp.size == W * rec
+        out = ctx.msm_combine(curve.cid, n, allp)
+    finally:
+        ctx.set_option("window_bits", 0)
+    assert canon(curve, out) == exp
+    ds.free(); dp.free()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_lhs_multi_slab_digit_stride(fctx, curve):
+    """regression: with several slabs per call the position-major digit matrix keeps the row stride
+    of the WHOLE call; slab_bits = 12 and n = 3*4096+5 make four slabs"""
+    ctx = fctx
+    n, base = 3 * 4096 + 5, 5
+    pts = cref.gen_points(curve.cid, 711, n); sc = cref.gen_scalars(curve.cid, 712, n, half=True)
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    ecarry, ecarries = cref.lhs_msm(curve.cid, sc, cref.aff_to_jac(curve.cid, pts), base)
+    ctx.set_option("slab_bits", 12)
+    try:
+        carry, carries = ctx.lhs_msm_device(curve.cid, ds.ptr, dp.ptr, n, base)
+    finally:
+        ctx.set_option("slab_bits", 0)
+    assert canon(curve, carry) == canon(curve, ecarry)
+    for i in range(carries.shape[0]):
+        assert canon(curve, carries[i]) == canon(curve, ecarries[i]), i
+
+
+def test_lhs_above_one_slab(ctx):
+    """n > 2^24 on the negabase path (two slabs at the default slab size): final carry and first carry by the walk identity"""
+    curve = pyref.GRUMPKIN
+    n, base = (1 << 24) + 4097, 16
+    q = cref.gen_points(curve.cid, 811, 1)[0]
+    dp = ctx.gen_walk(curve.cid, q, n)
+    sc = cref.gen_scalars(curve.cid, 812, n, half=True)
+    ds = ctx.to_device(sc)
+    carry, carries = ctx.lhs_msm_device(curve.cid, ds.ptr, dp.ptr, n, base)
+    assert canon(curve, carry) == canon(curve, cref.scalar_mul(curve.cid, cref.walk_dot(curve.cid, sc), q))
+    d = api.num_digits(curve.cid, base)
+    digs = ctx.negbase_decompose_batch(sc, base, d)
+    exp = _walk_carries_expected(curve, digs, d, base, q)
+    for i in (0, 1, d - 1):
+        assert canon(curve, carries[i]) == canon(curve, cref.scalar_mul(curve.cid, exp[i], q)), i
+    ds.free(); dp.free()
+
+
+def test_partial_entries_accept_empty_ranges(ctx):
+    """a rank beyond the last window / digit position (world > W) owns an empty range: no output, no error"""
+    curve = pyref.BN254_G1
+    n = 500
+    pts = cref.gen_points(curve.cid, 911, n); sc = cref.gen_scalars(curve.cid, 912, n, half=True)
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    W, _ = ctx.msm_plan(curve.cid, n)
+    assert ctx.msm_partial_device(curve.cid, ds.ptr, dp.ptr, n, W, W).size == 0
+    assert ctx.msm_partial_device(curve.cid, ds.ptr, dp.ptr, n, 3, 3).size == 0
+    d, _ = ctx.lhs_plan(curve.cid, 16)
+    assert ctx.lhs_partial_device(curve.cid, ds.ptr, dp.ptr, n, 16, d, d).size == 0
+
+
+def test_negbase_truncation_is_counted(ctx):
+    """digits beyond d are dropped like `.take(d)` (src/argument_witness_calc.rs:99); the count of scalars it happened to is exposed"""
+    sc = np.zeros((4, 32), np.uint8)
+    sc[0, 0] = 1; sc[1, :2] = 255; sc[2, :8] = 255; sc[3, :15] = 255
+    ctx.negbase_decompose_batch(sc, 16, 40)
+    assert ctx.last_truncated_count() == 0
+    digs = ctx.negbase_decompose_batch(sc, 16, 5)
+    assert ctx.last_truncated_count() == 2
+    assert digs.shape == (4, 5)
