@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--base", type=int, default=16)
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 of the cpu_baseline sample size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["rccl-abi", "torch"], default="rccl-abi",
+                    help="N > 1 window sharding: the C ABI's own RCCL communicator (lemsm_comm_init / lemsm_*_sharded_device: one "
+                         "ncclAllGather of raw device records) or the host-side torch.distributed all-gather of halo2_liam_eagen_msm_amd.dist")
     ap.add_argument("--sharding", choices=["windows", "points"], default="windows",
                     help="N > 1 partition of the MSM: Pippenger windows (north star, default) or pairs (SURVEY 8e alternative)")
     args = ap.parse_args()
@@ -131,9 +134,13 @@ def main():
     d_points = ctx.gen_walk(cid, q, n)   # P_i = (i+1) Q: sum s_i P_i == (sum s_i (i+1)) Q, the closed form verify_timed_result checks
     t_in = time.time() - t_in
 
-    if world > 1 and args.workload == "msm" and args.sharding == "windows":
-        # 16 windows split evenly over 2/4/8 ranks; the single-GPU default at 2^24 (15 windows of 17 bits) does not
-        ctx.set_option("window_bits", 16)
+    exchange = "none"
+    if world > 1 and args.sharding == "windows":
+        exchange = init_exchange(ctx, args.exchange, world, rank, dist, torch, coll_dev)
+        if exchange == "torch" and args.workload == "msm":
+            # 16 windows split evenly over 2/4/8 ranks; the single-GPU default at 2^24 (15 windows of 17 bits) does not
+            # (the C ABI's sharded entry pins this itself)
+            ctx.set_option("window_bits", 16)
 
     def step():
         if args.workload == "msm":
@@ -141,9 +148,13 @@ def main():
                 return ctx.msm_device(cid, d_scalars.ptr, d_points.ptr, n)
             if args.sharding == "points":
                 return ldist.sharded_msm_by_points(ctx, cid, d_scalars.ptr, d_points.ptr, n, world, rank, coll_dev)
+            if exchange == "rccl-abi":
+                return ctx.msm_sharded_device(cid, d_scalars.ptr, d_points.ptr, n)
             return ldist.sharded_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, world, rank, coll_dev)
         if world == 1:
             return ctx.lhs_msm_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True)[0]
+        if exchange == "rccl-abi":
+            return ctx.lhs_msm_sharded_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True)[0]
         return ldist.sharded_lhs_msm(ctx, cid, d_scalars.ptr, d_points.ptr, n, args.base, world, rank, coll_dev)[0]
 
     def sync():
@@ -219,6 +230,8 @@ def main():
                        else ("%s compute_lhs_witness MSM core, 2^%d points, negabase B=%d (w=4), half-width scalars" % (curve, logn, args.base)),
                        "n": n, "curve": curve, "sharding": ("pairs x%d" if (args.sharding == "points" and args.workload == "msm") else "pippenger-window x%d") % world,
                        "baseline_config": baseline_config(args.workload, curve, logn, world, args.base),
+                       "exchange": {"none": "single GPU", "rccl-abi": "C ABI: lemsm_comm_init + ncclAllGather of raw device records (librccl by dlopen)",
+                                    "torch": "torch.distributed all_gather_into_tensor of host-reduced window sums"}[exchange] if args.sharding == "windows" else "torch.distributed all-gather of one Jacobian partial per rank",
                        "input_gen_s": round(t_in, 2)},
             "roofline": roofline,
         }
@@ -247,6 +260,56 @@ def pmc_traffic(workload, curve, logn, world):
     key = "%s/%s/2^%d/x%d" % (workload, curve, logn, world)
     ent = table.get(key)
     return None if ent is None else ent["bytes_per_launch"]
+
+
+def host_threads():
+    """CPU threads this process may actually use: the smaller of the visible CPUs, the affinity mask and the cgroup quota
+    (a one-GPU share of the box is 16 of its 256 hardware threads)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def init_exchange(ctx, want, world, rank, dist, torch, coll_dev):
+    """N > 1: bring up the C ABI's RCCL communicator (unique id from rank 0, sent over the launcher's process group).
+    Every rank ends up with the same answer: "rccl-abi" if all of them joined, else "torch" (printed to stderr)."""
+    if want != "rccl-abi":
+        return "torch"
+    from halo2_liam_eagen_msm_amd import comm_unique_id
+    dev = coll_dev if coll_dev is not None else "cpu"
+    payload = np.zeros(129, np.uint8)
+    if rank == 0:
+        try:
+            payload[:128] = np.frombuffer(comm_unique_id(), np.uint8)
+            payload[128] = 1
+        except Exception as e:      # librccl not loadable through the library: fall back, loudly
+            print("bench: lemsm_comm_unique_id failed (%s); falling back to the torch.distributed exchange" % e, file=sys.stderr, flush=True)
+    t = torch.from_numpy(payload).to(dev)
+    dist.broadcast(t, 0)
+    payload = t.cpu().numpy()
+    ok = int(payload[128])
+    if ok:
+        try:
+            ctx.comm_init(payload[:128].tobytes(), world, rank)
+        except Exception as e:
+            print("bench: rank %d lemsm_comm_init failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32).to(dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return "rccl-abi"
+    if ok:
+        ctx.comm_destroy()
+    return "torch"
 
 
 def valu_model():
@@ -293,7 +356,7 @@ def cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args, world):
            parallel loop), one thread."""
     from oracle import cref
     if args.workload == "msm":
-        cores = os.cpu_count() or 1
+        cores = host_threads()
         slog = args.cpu_sample_log if args.cpu_sample_log is not None else min(logn, 21 if world == 1 else 19)
     else:
         cores = 1

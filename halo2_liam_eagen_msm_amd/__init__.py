@@ -8,4 +8,5 @@ from .api import (  # noqa: F401
     BN254_G1, GRUMPKIN, Context, DeviceBuffer, LemsmError, LengthMismatch, ScalarOutOfRange, BadBase,
     best_multiexp, compute_lhs_witness, compute_lhs_witness_inputs, negbase_decompose, precompute_multiplicities,
     jacobian_to_canonical, jacobian_sum, logb_ceil, order, num_digits, id_by_digit, digit_by_id,
+    Bases, Node, comm_unique_id,
 )

@@ -22,6 +22,8 @@ LEMSM_ERR_HIP = 5
 LEMSM_ERR_BAD_ARG = 6
 LEMSM_ERR_NOMEM = 7
 LEMSM_ERR_TOO_MANY_DIGITS = 8
+LEMSM_ERR_RCCL = 9
+LEMSM_COMM_ID_BYTES = 128
 
 BN254_G1 = 0
 GRUMPKIN = 1
@@ -41,6 +43,12 @@ SYMBOLS = [
     "lemsm_device_alloc", "lemsm_device_free", "lemsm_device_upload", "lemsm_device_download",
     "lemsm_device_gen_walk",
     "lemsm_debug_montmul", "lemsm_debug_fieldop", "lemsm_debug_pointop",
+    "lemsm_comm_unique_id", "lemsm_comm_init", "lemsm_comm_destroy", "lemsm_comm_info",
+    "lemsm_msm_sharded_device", "lemsm_lhs_msm_sharded_device",
+    "lemsm_node_create", "lemsm_node_destroy", "lemsm_node_size", "lemsm_node_ctx", "lemsm_node_last_error",
+    "lemsm_node_set_bases", "lemsm_node_msm", "lemsm_node_lhs_msm",
+    "lemsm_bases_upload", "lemsm_bases_free", "lemsm_bases_device_ptr", "lemsm_msm_with_bases",
+    "lemsm_debug_msm_sharded_sim", "lemsm_debug_lhs_sharded_sim",
 ]
 
 
@@ -109,6 +117,26 @@ def load() -> ctypes.CDLL:
         "lemsm_debug_montmul": (i, [vp, i, u64p, u64p, u64p, sz]),
         "lemsm_debug_fieldop": (i, [vp, i, i, u64p, u64p, u64p, sz]),
         "lemsm_debug_pointop": (i, [vp, i, i, u64p, u64p, u64p, sz]),
+        "lemsm_comm_unique_id": (i, [u8p]),
+        "lemsm_comm_init": (i, [vp, u8p, i, i]),
+        "lemsm_comm_destroy": (i, [vp]),
+        "lemsm_comm_info": (i, [vp, ctypes.POINTER(i), ctypes.POINTER(i)]),
+        "lemsm_msm_sharded_device": (i, [vp, i, vp, vp, sz, u64p]),
+        "lemsm_lhs_msm_sharded_device": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, u64p, u64p, szp]),
+        "lemsm_node_create": (i, [ctypes.POINTER(i), i, ctypes.POINTER(vp)]),
+        "lemsm_node_destroy": (None, [vp]),
+        "lemsm_node_size": (i, [vp]),
+        "lemsm_node_ctx": (vp, [vp, i]),
+        "lemsm_node_last_error": (ctypes.c_char_p, [vp]),
+        "lemsm_node_set_bases": (i, [vp, i, u64p, sz]),
+        "lemsm_node_msm": (i, [vp, u8p, sz, u64p]),
+        "lemsm_node_lhs_msm": (i, [vp, u8p, sz, ctypes.c_uint8, u64p, u64p, szp]),
+        "lemsm_bases_upload": (i, [vp, i, u64p, sz, ctypes.POINTER(vp)]),
+        "lemsm_bases_free": (None, [vp]),
+        "lemsm_bases_device_ptr": (vp, [vp]),
+        "lemsm_msm_with_bases": (i, [vp, vp, u8p, sz, u64p]),
+        "lemsm_debug_msm_sharded_sim": (i, [vp, i, vp, vp, sz, i, u64p]),
+        "lemsm_debug_lhs_sharded_sim": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, i, u64p, u64p, szp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -214,6 +214,64 @@ class Context:
         self._check(self.lib.lemsm_msm_combine(self.h, _curve_id(curve), n, _ptr(partials), _ptr(out)))
         return out
 
+    # ---- multi-GPU (RCCL behind the C ABI) ---------------------------------------------
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        """collective: every rank calls it with rank 0's comm_unique_id() (lemsm_comm_init = ncclCommInitRank)"""
+        buf = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        assert buf.size == _lib.LEMSM_COMM_ID_BYTES
+        self._check(self.lib.lemsm_comm_init(self.h, _ptr(buf), int(nranks), int(rank)))
+
+    def comm_destroy(self):
+        self._check(self.lib.lemsm_comm_destroy(self.h))
+
+    def comm_info(self) -> Tuple[int, int]:
+        n = ctypes.c_int(); r = ctypes.c_int()
+        self._check(self.lib.lemsm_comm_info(self.h, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
+
+    def msm_sharded_device(self, curve, d_scalars: int, d_points: int, n: int) -> np.ndarray:
+        """collective over the context's communicator: this rank's Pippenger windows, one ncclAllGather of the raw
+        device records, the combine; every rank returns the same Jacobian point"""
+        out = np.zeros(12, np.uint64)
+        self._check(self.lib.lemsm_msm_sharded_device(self.h, _curve_id(curve), d_scalars, d_points, n, _ptr(out)))
+        return out
+
+    def lhs_msm_sharded_device(self, curve, d_scalars: int, d_points_affine: int, n: int, base: int, want_carries: bool = True):
+        cid = _curve_id(curve)
+        d = num_digits(cid, base)
+        carry = np.zeros(12, np.uint64)
+        carries = np.zeros((d, 12), np.uint64) if want_carries else None
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_lhs_msm_sharded_device(self.h, cid, d_scalars, d_points_affine, n, base, _ptr(carry),
+                                                   _ptr(carries) if want_carries else None, ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return carry, carries
+
+    def debug_msm_sharded_sim(self, curve, d_scalars: int, d_points: int, n: int, world: int) -> np.ndarray:
+        out = np.zeros(12, np.uint64)
+        self._check(self.lib.lemsm_debug_msm_sharded_sim(self.h, _curve_id(curve), d_scalars, d_points, n, world, _ptr(out)))
+        return out
+
+    def debug_lhs_sharded_sim(self, curve, d_scalars: int, d_points_affine: int, n: int, base: int, world: int):
+        cid = _curve_id(curve)
+        d = num_digits(cid, base)
+        carry = np.zeros(12, np.uint64); carries = np.zeros((d, 12), np.uint64)
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_debug_lhs_sharded_sim(self.h, cid, d_scalars, d_points_affine, n, base, world, _ptr(carry), _ptr(carries),
+                                                  ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return carry, carries
+
+    # ---- resident bases ------------------------------------------------------------------
+    def bases_upload(self, curve, points_affine) -> "Bases":
+        return Bases(self, curve, points_affine)
+
+    def msm_with_bases(self, bases: "Bases", scalars) -> np.ndarray:
+        s = _scalars(scalars)
+        out = np.zeros(12, np.uint64)
+        self._check(self.lib.lemsm_msm_with_bases(self.h, bases.h, _ptr(s), s.shape[0], _ptr(out)))
+        return out
+
     # ---- negabase ------------------------------------------------------------------
     def negbase_decompose_batch(self, scalars, base: int, d: int) -> np.ndarray:
         s = _scalars(scalars)
@@ -312,6 +370,107 @@ class Context:
         out = np.zeros_like(acc)
         self._check(self.lib.lemsm_debug_pointop(self.h, _curve_id(curve), op, _ptr(acc), _ptr(q), _ptr(out), acc.shape[0]))
         return out
+
+
+class Bases:
+    """affine bases resident on one GPU (lemsm_bases_upload): later MSMs upload only their scalars"""
+
+    def __init__(self, ctx: Context, curve, points_affine):
+        p = _limbs(points_affine, 8)
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.lemsm_bases_upload(ctx.h, _curve_id(curve), _ptr(p), p.shape[0], ctypes.byref(h)))
+        self.ctx, self.h, self.n = ctx, h, p.shape[0]
+
+    @property
+    def ptr(self) -> int:
+        return self.ctx.lib.lemsm_bases_device_ptr(self.h)
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.lemsm_bases_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    """rank 0: the 128-byte RCCL unique id every rank passes to Context.comm_init"""
+    buf = np.zeros(_lib.LEMSM_COMM_ID_BYTES, np.uint8)
+    rc = _lib.load().lemsm_comm_unique_id(_ptr(buf))
+    if rc:
+        raise LemsmError(rc, "lemsm_comm_unique_id (is librccl loadable?)")
+    return buf.tobytes()
+
+
+class Node:
+    """All GPUs of one node from one process (lemsm_node_*): what a Rust host binds."""
+
+    def __init__(self, devices: Optional[Sequence[int]] = None, ndev: Optional[int] = None):
+        self.lib = _lib.load()
+        if devices is not None:
+            arr = (ctypes.c_int * len(devices))(*devices); nd = len(devices)
+        else:
+            arr = None; nd = int(ndev or 1)
+        h = ctypes.c_void_p()
+        rc = self.lib.lemsm_node_create(arr, nd, ctypes.byref(h))
+        if rc:
+            raise LemsmError(rc, "lemsm_node_create failed")
+        self.h = h
+
+    def _check(self, rc: int, bad_index: Optional[int] = None):
+        if rc == _lib.LEMSM_OK:
+            return
+        msg = self.lib.lemsm_node_last_error(self.h).decode() or self.lib.lemsm_strerror(rc).decode()
+        if rc == _lib.LEMSM_ERR_LEN_MISMATCH:
+            raise LengthMismatch(rc, "incompatible amount of coefficients")
+        if rc == _lib.LEMSM_ERR_SCALAR_OUT_OF_RANGE:
+            raise ScalarOutOfRange(rc, msg, bad_index if bad_index is not None else 0)
+        if rc == _lib.LEMSM_ERR_BAD_BASE:
+            raise BadBase(rc, msg)
+        raise LemsmError(rc, msg)
+
+    @property
+    def size(self) -> int:
+        return self.lib.lemsm_node_size(self.h)
+
+    def set_bases(self, curve, points_affine):
+        p = _limbs(points_affine, 8)
+        self._check(self.lib.lemsm_node_set_bases(self.h, _curve_id(curve), _ptr(p), p.shape[0]))
+        self.curve = _curve_id(curve)
+
+    def msm(self, scalars) -> np.ndarray:
+        s = _scalars(scalars)
+        out = np.zeros(12, np.uint64)
+        self._check(self.lib.lemsm_node_msm(self.h, _ptr(s), s.shape[0], _ptr(out)))
+        return out
+
+    def lhs_msm(self, scalars, base: int, want_carries: bool = True):
+        s = _scalars(scalars)
+        if not (3 <= base <= 255):
+            raise BadBase(_lib.LEMSM_ERR_BAD_BASE, "base must be in 3..=255")
+        d = num_digits(self.curve, base)
+        carry = np.zeros(12, np.uint64)
+        carries = np.zeros((d, 12), np.uint64) if want_carries else None
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_node_lhs_msm(self.h, _ptr(s), s.shape[0], base, _ptr(carry), _ptr(carries) if want_carries else None,
+                                         ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return carry, carries
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lemsm_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def jacobian_to_canonical(curve, jac) -> bytes:

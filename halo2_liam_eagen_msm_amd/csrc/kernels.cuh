@@ -466,7 +466,8 @@ __global__ void k_copy_points(const CopyTask* __restrict__ tasks, u32 ntasks, u3
 __global__ __launch_bounds__(256) void k_negbase_digits(const uint4* __restrict__ scalars, u32 n, u32 base, u32 d,
                                                         const u32* __restrict__ bound /*8 limbs*/, int check_range,
                                                         uint8_t* __restrict__ digits, uint8_t* __restrict__ digitsT,
-                                                        u32* __restrict__ err) {
+                                                        u32* __restrict__ err, u32 row_begin, u32 row_end /* rows of digitsT to write:
+                                                        a digit-position-sharded rank stores only the rows it will sort */) {
   u32 j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   uint4 a = scalars[2 * (size_t)j], b = scalars[2 * (size_t)j + 1];
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void k_negbase_digits(const uint4* __restrict_
     for (int k = 0; k < 16; k++) nz |= h[k];
     if (!nz) neg = false;
     if (digits) digits[(size_t)j * d + i] = (uint8_t)digit;
-    if (digitsT) digitsT[(size_t)i * n + j] = (uint8_t)digit;
+    if (digitsT && i >= row_begin && i < row_end) digitsT[(size_t)i * n + j] = (uint8_t)digit;
   }
   // digits beyond d are truncated exactly like chain(repeat(0)).take(d) at
   // src/argument_witness_calc.rs:99; err[1] counts scalars whose expansion did not fit

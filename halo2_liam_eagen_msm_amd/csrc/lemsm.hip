@@ -15,6 +15,9 @@
 #include "../../include/lemsm.h"
 #include "hostmath.hpp"
 #include "kernels.cuh"
+#include "rccl_dyn.hpp"
+#include <functional>
+#include <thread>
 
 using namespace lemsm;
 
@@ -87,6 +90,9 @@ struct lemsm_ctx {
   DevBuf in_s;      // staged scalars (host-pointer entries)
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
+  DevBuf gather;    // multi-GPU: all ranks' raw per-window records after the all-gather
+  ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
+  int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;
   long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0;
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
@@ -163,7 +169,7 @@ u32 choose_c(const lemsm_ctx* ctx, size_t n) {
   // points per slab: 6 % less accumulation, 0.5 ms more sort + tail -> 3 % faster end to end at
   // 2^24, a wash below (profiles/r01/p_c16_vs_c17_one_group.txt).  Window-sharded multi-GPU runs
   // pin 16 (bench.py sets window_bits = 16 for them): 16 windows split evenly over 2/4/8 ranks, 15 do not.
-  if (lg >= 24) return 17;
+  if (lg >= 24) return (ctx && ctx->plan_world > 1) ? 16u : 17u;
   int c = (int)lg - 3;
   if (c < 3) c = 3;
   if (c > 16) c = 16;
@@ -626,13 +632,23 @@ void from_device_records(const std::vector<char>& raw, std::vector<host::pt>& ou
   }
 }
 
+// One call's raw per-window records on the device: nslabs blocks of out_slab bytes, block k holding the
+// records [total, U_0..U_{L-1}] of windows wb.. of slab k (nw_pad windows' worth of room, unused tail zeroed).
+struct WinRun {
+  size_t nslabs = 0, ng = 0, out_slab = 0, SLAB = 0, err_slot = 0;
+  char* d_out = nullptr; char* d_err = nullptr;
+  u32 nw = 0, nw_pad = 0, L = 0; size_t ptb = 0;
+  size_t send_bytes() const { return out_slab * nslabs; }
+};
+
+// Enqueues the whole pipeline of one call (every slab, every window group) on the context's queues and leaves the
+// raw records in the workspace (wr.d_out); nothing is read back.  nw_pad >= we - wb sizes the record area per slab
+// (multi-GPU: the same for every rank, so that the all-gather sends equal counts).
 template <class P64, class G, class MakeSrc>
-int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 wb, u32 we, u32 d,
-                const void* d_points, std::vector<host::pt>& host_out) {
-  typedef host::HG<P64> HGp;
+int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 wb, u32 we, u32 d,
+                        const void* d_points, u32 nw_pad, WinRun& wr) {
   u32 nw = we - wb;
-  host_out.assign((size_t)nw * (L + 1), HGp::identity());
-  if (n == 0 || nw == 0) return LEMSM_OK;
+  if (nw_pad < nw) nw_pad = nw;
   // Slabs of points: every slab runs the whole pipeline and the per-window records of the slabs
   // are added on the host.  Device-resident inputs use the largest slab the 32-bit entry format
   // allows; host-pointer entries (ctx->host_stage) use small slabs so that the PCIe upload of slab
@@ -642,7 +658,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   u32 slab_log = ctx->opt_slab_bits ? (u32)ctx->opt_slab_bits : MAX_SLAB_LOG;
   if (hs) slab_log = host_slab_log(ctx, n);
   const size_t SLAB = (size_t)1 << slab_log;
-  const size_t nslabs = (n + SLAB - 1) / SLAB;
+  const size_t nslabs = n ? (n + SLAB - 1) / SLAB : 1;
   u32 gmax = max_group_windows(nb);
   const size_t ptb = G::PT_BYTES;
   // Window groups of this call.  Default: as few as the bin limit allows (one at c = 16).  With
@@ -650,12 +666,12 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   // measured (profiles/r01/pipelined_groups_trace.txt) this does NOT pay on MI355X: k_accum1 is
   // power-bound, so sort kernels running beside it slow it down by as much as they hide.
   u32 ngroups = 1;
-  if (ctx->opt_groups > 0) ngroups = std::min((u32)ctx->opt_groups, nw);
-  u32 gsz = std::min(gmax, (nw + ngroups - 1) / ngroups);
+  if (ctx->opt_groups > 0) ngroups = std::min((u32)ctx->opt_groups, std::max(nw, 1u));
+  u32 gsz = std::max(1u, std::min(gmax, (nw + ngroups - 1) / ngroups));
   struct Grp { u32 g0, g1; size_t off; };
   std::vector<Grp> groups;
   size_t ws_total = 0;
-  {
+  if (n) {
     // a group's workspace must hold the layout of EVERY slab: the ragged last slab can need more of some
     // buffers than a full one (below 2^16 points the pass-1 ranges shrink, so there are more of them)
     u32 sn0 = (u32)std::min(SLAB, n), snl = (u32)(n - (nslabs - 1) * SLAB);
@@ -668,9 +684,9 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     }
   }
   const size_t ng = groups.size();
-  const size_t out_slab = align_up((size_t)nw * (L + 1) * ptb, 256);   // one slab's records
+  const size_t out_slab = align_up((size_t)std::max(nw_pad, 1u) * (L + 1) * ptb, 256);   // one slab's records
   const size_t ERR_SLOT = 64;   // per (slab, group): err[2] of the digit pass, then k_accum1's clock stamps (4 x u64) at byte 16
-  const size_t err_bytes = align_up(nslabs * ng * ERR_SLOT, 256);
+  const size_t err_bytes = align_up(std::max<size_t>(nslabs * ng, 1) * ERR_SLOT, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
   int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nslabs + err_bytes + 4096);
   if (rc) return rc;
@@ -678,6 +694,8 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   char* d_conv = ws_base + ws_total;
   char* d_out = d_conv + conv_bytes;
   char* d_err = d_out + out_slab * nslabs;
+  wr.nslabs = nslabs; wr.ng = ng; wr.out_slab = out_slab; wr.SLAB = SLAB; wr.err_slot = ERR_SLOT;
+  wr.d_out = d_out; wr.d_err = d_err; wr.nw = nw; wr.nw_pad = nw_pad; wr.L = L; wr.ptb = ptb;
   while (ctx->evpool.size() < 3 * ng * nslabs + (hs ? nslabs : 0)) {
     hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e);
   }
@@ -690,12 +708,15 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   HIPCHK(ctx, hipStreamSynchronize(s_acc));   // inputs staged / digits produced on the main stream are complete
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s_acc));
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
-  for (size_t k = 0; k < nslabs; k++) {
+  if (nw_pad != nw || n == 0 || nw == 0)      // record slots no kernel writes (a rank with fewer windows than the widest one) read as identities
+    HIPCHK(ctx, hipMemsetAsync(d_out, 0, out_slab * nslabs, s_acc));
+  for (size_t k = 0; k < nslabs && n && nw; k++) {
     const size_t s0 = k * SLAB;
     u32 sn = (u32)std::min(SLAB, n - s0);
     if (hs) {
       HIPCHK(ctx, hipMemcpyAsync(hs->d_scalars + s0 * 32, hs->h_scalars + s0 * 32, (size_t)sn * 32, hipMemcpyHostToDevice, s_up));
-      HIPCHK(ctx, hipMemcpyAsync(hs->d_points + s0 * 64, (const char*)hs->h_points + s0 * 64, (size_t)sn * 64, hipMemcpyHostToDevice, s_up));
+      if (hs->h_points)   // (null: the bases are resident already, lemsm_msm_with_bases)
+        HIPCHK(ctx, hipMemcpyAsync(hs->d_points + s0 * 64, (const char*)hs->h_points + s0 * 64, (size_t)sn * 64, hipMemcpyHostToDevice, s_up));
       HIPCHK(ctx, hipEventRecord(ev_up[k], s_up));
       HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_up[k], 0));
     }
@@ -742,38 +763,77 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
     }
     // one queue: the slabs' kernels are stream-ordered, so the workspace is reused without a drain
   }
-  std::vector<char> raw(out_slab * nslabs);
-  std::vector<u32> errw(nslabs * ng * (ERR_SLOT / 4));
-  HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_out, raw.size(), hipMemcpyDeviceToHost, s_tail));
-  HIPCHK(ctx, hipMemcpyAsync(errw.data(), d_err, errw.size() * 4, hipMemcpyDeviceToHost, s_tail));
+  if (n == 0 || nw == 0) { wr.ng = 0; }
+  return LEMSM_OK;
+}
+
+// The queue the records of run_windows_enqueue become final on (where a collective or the read-back is enqueued).
+hipStream_t records_stream(const lemsm_ctx* ctx) { return ctx->opt_groups <= 1 ? ctx->stream : ctx->stream_tail; }
+
+// Reads back `raw_bytes` of records from d_raw (wr.d_out, or the gathered buffer of a multi-GPU call) and this call's
+// error / clock words, waits, and turns the digit pass's flags into the reference's panic sites.
+int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size_t raw_bytes, std::vector<char>& raw) {
+  hipStream_t s_tail = records_stream(ctx);
+  raw.resize(raw_bytes);
+  const size_t nerr = wr.nslabs * wr.ng;
+  std::vector<u32> errw(std::max<size_t>(nerr, 1) * (wr.err_slot / 4));
+  if (raw_bytes) HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_raw, raw_bytes, hipMemcpyDeviceToHost, s_tail));
+  if (nerr) HIPCHK(ctx, hipMemcpyAsync(errw.data(), wr.d_err, nerr * wr.err_slot, hipMemcpyDeviceToHost, s_tail));
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s_tail));
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
   float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
   ctx->t_total_ms = ms;
-  for (size_t k = 0; k < nslabs; k++)   // non-canonical scalars (>= field order) are rejected, never bucketed
-    for (size_t gi = 0; gi < ng; gi++) {
-      const u32* ew = errw.data() + (k * ng + gi) * (ERR_SLOT / 4);
+  for (size_t k = 0; k < wr.nslabs; k++)   // non-canonical scalars (>= field order) are rejected, never bucketed
+    for (size_t gi = 0; gi < wr.ng; gi++) {
+      const u32* ew = errw.data() + (k * wr.ng + gi) * (wr.err_slot / 4);
       if (ew[0]) {
-        ctx->bad_index = k * SLAB + (size_t)(~ew[1]);
+        ctx->bad_index = k * wr.SLAB + (size_t)(~ew[1]);
         return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
       }
     }
   u64 clk_cyc = 0, clk_ticks = 0;
-  for (size_t i = 0; i < nslabs * ng; i++) {
+  for (size_t i = 0; i < nerr; i++) {
     float a = 0; HIPCHK(ctx, hipEventElapsedTime(&a, ctx->evpool[3 * i + 1], ctx->evpool[3 * i + 2]));
     ctx->t_accum_ms += a; ctx->n_accum++;
-    u64 ck[4]; memcpy(ck, errw.data() + i * (ERR_SLOT / 4) + 4, 32);
+    u64 ck[4]; memcpy(ck, errw.data() + i * (wr.err_slot / 4) + 4, 32);
     if (ck[2] > ck[0] && ck[3] > ck[1] && ck[2] - ck[0] < ((u64)1 << 40)) { clk_cyc += ck[2] - ck[0]; clk_ticks += ck[3] - ck[1]; }
   }
   ctx->accum_clock_mhz = clk_ticks ? (double)clk_cyc / (double)clk_ticks * 100.0 : 0.0;
+  return LEMSM_OK;
+}
+
+// host: records of nw windows = sum over the slabs of one rank's record area (raw: nslabs blocks of out_slab bytes)
+template <class P64, class G>
+void sum_slab_records(const char* raw, size_t out_slab, size_t nslabs, u32 nw, u32 L, std::vector<host::pt>& host_out) {
+  typedef host::HG<P64> HGp;
+  const size_t ptb = G::PT_BYTES;
+  host_out.assign((size_t)nw * (L + 1), HGp::identity());
   std::vector<host::pt> tmp;
   std::vector<char> one((size_t)nw * (L + 1) * ptb);
-  for (size_t k = 0; k < nslabs; k++) {
-    memcpy(one.data(), raw.data() + k * out_slab, one.size());
+  for (size_t k = 0; k < nslabs && nw; k++) {
+    memcpy(one.data(), raw + k * out_slab, one.size());
     from_device_records<P64, G>(one, tmp);
     if (k == 0) host_out = tmp;
     else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = HGp::add(host_out[i], tmp[i]);
   }
+}
+
+// Generic windowed bucket pipeline over window range [wb,we): fills host_out with
+// (we-wb) x (L+1) XYZZ points, summed over slabs.
+template <class P64, class G, class MakeSrc>
+int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 wb, u32 we, u32 d,
+                const void* d_points, std::vector<host::pt>& host_out) {
+  typedef host::HG<P64> HGp;
+  u32 nw = we - wb;
+  host_out.assign((size_t)nw * (L + 1), HGp::identity());
+  if (n == 0 || nw == 0) return LEMSM_OK;
+  WinRun wr;
+  int rc = run_windows_enqueue<P64, G>(ctx, make_src, n, c, nb, nbp, L, W, wb, we, d, d_points, nw, wr);
+  if (rc) return rc;
+  std::vector<char> raw;
+  rc = run_windows_finish(ctx, wr, wr.d_out, wr.send_bytes(), raw);
+  if (rc) return rc;
+  sum_slab_records<P64, G>(raw.data(), wr.out_slab, wr.nslabs, nw, L, host_out);
   return LEMSM_OK;
 }
 
@@ -867,7 +927,7 @@ int make_lhs_plan(int curve, u32 base, LhsPlan& lp) {
 // digits (position-major, d x n) for the lhs path; leaves err words in ctx workspace tail
 struct LhsDigits { uint8_t* digitsT; u32* err; };
 
-int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const LhsPlan& lp, DevBuf& buf, LhsDigits& out) {
+int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const LhsPlan& lp, DevBuf& buf, LhsDigits& out, u32 row_begin, u32 row_end) {
   size_t bytes = align_up((size_t)lp.d * n, 256) + 256 + 64;
   int rc = reserve(ctx, buf, bytes);
   if (rc) return rc;
@@ -880,7 +940,7 @@ int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const
   HIPCHK(ctx, hipMemcpyAsync(bound_d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (n) hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)d_scalars, (u32)n,
-                            lp.base, lp.d, bound_d, 1, (uint8_t*)nullptr, out.digitsT, out.err);
+                            lp.base, lp.d, bound_d, 1, (uint8_t*)nullptr, out.digitsT, out.err, row_begin, row_end);
   HIPCHK(ctx, hipGetLastError());
   return LEMSM_OK;
 }
@@ -891,7 +951,7 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   if (pb > pe || pe > lp.d) return fail(ctx, LEMSM_ERR_BAD_ARG, "position range out of bounds");
   if (n >= ((size_t)1 << 32)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
   LhsDigits dg;
-  int rc = lhs_digits(ctx, curve, d_scalars, n, lp, ctx->in_aux, dg);
+  int rc = lhs_digits(ctx, curve, d_scalars, n, lp, ctx->in_aux, dg, pb, pe);
   if (rc) return rc;
   // the digit matrix is position-major over the whole n; slabs index it with an offset
   auto make_src = [&](size_t s0, u32) { NegProvider s; s.digitsT = dg.digitsT + s0; return s; };
@@ -946,6 +1006,143 @@ int lhs_partial_dispatch(lemsm_ctx* ctx, int curve, const void* d_scalars, const
   }
   if (curve == LEMSM_BN254_G1) return lhs_partial_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, lp, pb, pe, out, bad_index);
   return lhs_partial_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, lp, pb, pe, out, bad_index);
+}
+
+// ---- multi-GPU: window / digit-position sharding with ONE all-gather of raw device records -------------------
+// Rank r of `world` owns windows [W r / world, W (r+1) / world).  Every rank runs the pipeline for its windows over
+// ALL points (replicated in its HBM), leaves the raw records [total, U_0..U_{L-1}] of each window (per slab) in its
+// workspace, and ncclAllGather moves them device-to-device over xGMI -- no host round trip before the exchange.
+// Every rank then reads the gathered buffer back once and runs the same fused host Horner.  EC addition is not an RCCL
+// reduction operator, hence all-gather + local combine.  `sim` (tests / one-GPU rehearsal): the ranks' pipelines
+// run one after the other on this GPU and their record areas are copied into the gathered buffer where the
+// collective would have put them, so everything but the ncclAllGather call itself is exercised.
+struct Exchange { int world, rank; bool sim; };
+
+#define RCCLCHK(ctx, expr)                                                                     \
+  do {                                                                                         \
+    ncclResult_t r_ = (expr);                                                                  \
+    if (r_ != ncclSuccess) {                                                                   \
+      (ctx)->last_error = std::string(#expr) + ": " + Rccl::get().GetErrorString(r_);          \
+      return LEMSM_ERR_RCCL;                                                                   \
+    }                                                                                          \
+  } while (0)
+
+inline void shard_range(u32 W, int world, int r, u32& a, u32& b) {
+  a = (u32)((u64)W * (u64)r / (u64)world); b = (u32)((u64)W * (u64)(r + 1) / (u64)world);
+}
+
+// shared by the MSM and the lhs path: runs the rank's (or, simulated, every rank's) windows and returns the records of
+// ALL W windows (W x (L+1) host points, slabs summed)
+template <class P64, class G, class MakeSrc>
+int sharded_records(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 d, const void* d_points,
+                    const Exchange& ex, std::vector<host::pt>& all) {
+  u32 max_nw = 0;
+  for (int r = 0; r < ex.world; r++) { u32 a, b; shard_range(W, ex.world, r, a, b); max_nw = std::max(max_nw, b - a); }
+  WinRun wr; std::vector<char> raw;
+  size_t sb = 0;
+  if (!ex.sim) {
+    u32 a, b; shard_range(W, ex.world, ex.rank, a, b);
+    int rc = run_windows_enqueue<P64, G>(ctx, make_src, n, c, nb, nbp, L, W, a, b, d, d_points, max_nw, wr);
+    if (rc) return rc;
+    sb = wr.send_bytes();
+    rc = reserve(ctx, ctx->gather, sb * ex.world); if (rc) return rc;
+    RCCLCHK(ctx, Rccl::get().AllGather(wr.d_out, ctx->gather.p, sb, ncclUint8, ctx->comm, records_stream(ctx)));
+    rc = run_windows_finish(ctx, wr, (const char*)ctx->gather.p, sb * ex.world, raw);
+    if (rc) return rc;
+  } else {
+    double t_total = 0, t_acc = 0; int n_acc = 0;
+    for (int r = 0; r < ex.world; r++) {
+      u32 a, b; shard_range(W, ex.world, r, a, b);
+      int rc = run_windows_enqueue<P64, G>(ctx, make_src, n, c, nb, nbp, L, W, a, b, d, d_points, max_nw, wr);
+      if (rc) return rc;
+      sb = wr.send_bytes();
+      if (r == 0) { rc = reserve(ctx, ctx->gather, sb * ex.world); if (rc) return rc; }
+      HIPCHK(ctx, hipMemcpyAsync((char*)ctx->gather.p + (size_t)r * sb, wr.d_out, sb, hipMemcpyDeviceToDevice, records_stream(ctx)));
+      std::vector<char> none;
+      rc = run_windows_finish(ctx, wr, nullptr, 0, none);
+      if (rc) return rc;
+      t_total += ctx->t_total_ms; t_acc += ctx->t_accum_ms; n_acc += ctx->n_accum;
+    }
+    ctx->t_total_ms = t_total; ctx->t_accum_ms = t_acc; ctx->n_accum = n_acc;
+    raw.resize(sb * ex.world);
+    HIPCHK(ctx, hipMemcpy(raw.data(), ctx->gather.p, raw.size(), hipMemcpyDeviceToHost));
+  }
+  all.assign((size_t)W * (L + 1), host::HG<P64>::identity());
+  std::vector<host::pt> part;
+  for (int r = 0; r < ex.world; r++) {
+    u32 a, b; shard_range(W, ex.world, r, a, b);
+    if (a == b) continue;
+    sum_slab_records<P64, G>(raw.data() + (size_t)r * sb, wr.out_slab, wr.nslabs, b - a, L, part);
+    std::copy(part.begin(), part.end(), all.begin() + (size_t)a * (L + 1));
+  }
+  return LEMSM_OK;
+}
+
+template <class P64, class G>
+int msm_sharded_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, const Exchange& ex, u64 out[12]) {
+  MsmPlan mp = make_msm_plan(ctx, curve, n);
+  auto make_src = [&](size_t s0, u32) {
+    PipProvider s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
+    memcpy(s.kadd.k, mp.kadd, 32); memcpy(s.kadd.order, order_of(curve), 32); return s;
+  };
+  std::vector<host::pt> all;
+  int rc = sharded_records<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, 0, d_points, ex, all);
+  if (rc) return rc;
+  msm_combine_raw_t<P64>(mp, all.data(), out);
+  return LEMSM_OK;
+}
+
+template <class P64, class G>
+int lhs_sharded_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, const LhsPlan& lp,
+                  const Exchange& ex, u64 out_carry[12], u64* out_carries, size_t* bad_index) {
+  if (n >= ((size_t)1 << 32)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  u32 pb = 0, pe = lp.d;
+  if (!ex.sim) shard_range(lp.d, ex.world, ex.rank, pb, pe);
+  LhsDigits dg;
+  int rc = lhs_digits(ctx, curve, d_scalars, n, lp, ctx->in_aux, dg, pb, pe);   // every rank range-checks every scalar; it stores its own rows only
+  if (rc) return rc;
+  auto make_src = [&](size_t s0, u32) { NegProvider s; s.digitsT = dg.digitsT + s0; return s; };
+  std::vector<host::pt> all;
+  rc = sharded_records<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, lp.d, d_points, ex, all);
+  if (rc) return rc;
+  u32 err[2] = {0xffffffffu, 0};
+  if (n) {
+    HIPCHK(ctx, hipMemcpyAsync(err, dg.err, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->truncated = err[1];
+  if (err[0] != 0xffffffffu) {
+    if (bad_index) *bad_index = err[0];
+    return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar out of range (>= isqrt(order)+2)");
+  }
+  std::vector<host::pt> sums(lp.d);
+  for (u32 w = 0; w < lp.d; w++) sums[w] = window_sum<P64>(all.data() + (size_t)w * (lp.L + 1), lp.L);
+  lhs_combine_t<P64>(lp, sums.data(), out_carry, out_carries);
+  return LEMSM_OK;
+}
+
+int msm_sharded_dispatch(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, const Exchange& ex, u64 out[12]) {
+  if (n == 0) { memset(out, 0, 96); return LEMSM_OK; }
+  int saved = ctx->plan_world; ctx->plan_world = ex.world;
+  int rc;
+  if (ctx->opt_field == 1) {
+    rc = curve == LEMSM_BN254_G1 ? msm_sharded_t<host::FqParams64, GqStrict>(ctx, curve, d_scalars, d_points, n, ex, out)
+                                 : msm_sharded_t<host::FrParams64, GrStrict>(ctx, curve, d_scalars, d_points, n, ex, out);
+  } else {
+    rc = curve == LEMSM_BN254_G1 ? msm_sharded_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, ex, out)
+                                 : msm_sharded_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, ex, out);
+  }
+  ctx->plan_world = saved;
+  return rc;
+}
+int lhs_sharded_dispatch(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, const LhsPlan& lp,
+                         const Exchange& ex, u64 out_carry[12], u64* out_carries, size_t* bad_index) {
+  if (ctx->opt_field == 1) {
+    if (curve == LEMSM_BN254_G1) return lhs_sharded_t<host::FqParams64, GqStrict>(ctx, curve, d_scalars, d_points, n, lp, ex, out_carry, out_carries, bad_index);
+    return lhs_sharded_t<host::FrParams64, GrStrict>(ctx, curve, d_scalars, d_points, n, lp, ex, out_carry, out_carries, bad_index);
+  }
+  if (curve == LEMSM_BN254_G1) return lhs_sharded_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, lp, ex, out_carry, out_carries, bad_index);
+  return lhs_sharded_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, lp, ex, out_carry, out_carries, bad_index);
 }
 
 template <class F>
@@ -1062,6 +1259,7 @@ const char* lemsm_strerror(int s) {
     case LEMSM_ERR_BAD_ARG: return "bad argument";
     case LEMSM_ERR_NOMEM: return "out of device memory";
     case LEMSM_ERR_TOO_MANY_DIGITS: return "too many digits";
+    case LEMSM_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
   }
 }
@@ -1096,7 +1294,8 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   if (ctx->stream_sort) { (void)hipStreamSynchronize(ctx->stream_sort); (void)hipStreamDestroy(ctx->stream_sort); }
   if (ctx->stream_tail) { (void)hipStreamSynchronize(ctx->stream_tail); (void)hipStreamDestroy(ctx->stream_tail); }
   for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
-  for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux}) if (b->p) (void)hipFree(b->p);
+  if (ctx->comm) { (void)Rccl::get().CommDestroy(ctx->comm); ctx->comm = nullptr; }
+  for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1224,7 +1423,7 @@ int lemsm_negbase_decompose_batch(lemsm_ctx* ctx, const uint8_t* scalars, size_t
   HIPCHK(ctx, hipMemcpyAsync(b + dig_bytes, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)ctx->in_s.p, (u32)n,
-                     (u32)base, d, (const u32*)(b + dig_bytes), 0, (uint8_t*)b, (uint8_t*)nullptr, (u32*)(b + dig_bytes) + 8);
+                     (u32)base, d, (const u32*)(b + dig_bytes), 0, (uint8_t*)b, (uint8_t*)nullptr, (u32*)(b + dig_bytes) + 8, 0u, d);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(digits, b, (size_t)n * d, hipMemcpyDeviceToHost, ctx->stream));
   u32 errw[2] = {0, 0};
@@ -1312,6 +1511,258 @@ int lemsm_lhs_msm_grumpkin(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, 
 }
 int lemsm_lhs_msm_bn254_g1(lemsm_ctx* ctx, const uint8_t* s, const uint64_t* p, size_t n, uint8_t base, uint64_t oc[12], uint64_t* ocs, size_t* bad) {
   return lemsm_lhs_msm(ctx, LEMSM_BN254_G1, s, p, n, base, oc, ocs, bad);
+}
+
+// ---- multi-GPU entries ---------------------------------------------------------------------------------------
+int lemsm_comm_unique_id(uint8_t id[LEMSM_COMM_ID_BYTES]) {
+  if (!id) return LEMSM_ERR_BAD_ARG;
+  Rccl& R = Rccl::get();
+  if (!R.ok()) return LEMSM_ERR_RCCL;
+  static_assert(LEMSM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId u;
+  if (R.GetUniqueId(&u) != ncclSuccess) return LEMSM_ERR_RCCL;
+  memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return LEMSM_OK;
+}
+
+int lemsm_comm_init(lemsm_ctx* ctx, const uint8_t id[LEMSM_COMM_ID_BYTES], int nranks, int rank) {
+  if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return LEMSM_ERR_BAD_ARG;
+  Rccl& R = Rccl::get();
+  if (!R.ok()) return fail(ctx, LEMSM_ERR_RCCL, "RCCL not loadable: " + R.error);
+  if (ctx->comm) return fail(ctx, LEMSM_ERR_BAD_ARG, "context already has a communicator (lemsm_comm_destroy first)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId u; memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  RCCLCHK(ctx, R.CommInitRank(&ctx->comm, nranks, u, rank));
+  ctx->comm_size = nranks; ctx->comm_rank = rank;
+  return LEMSM_OK;
+}
+
+int lemsm_comm_destroy(lemsm_ctx* ctx) {
+  if (!ctx) return LEMSM_ERR_BAD_ARG;
+  if (ctx->comm) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ncclResult_t r = Rccl::get().CommDestroy(ctx->comm);
+    ctx->comm = nullptr; ctx->comm_size = 1; ctx->comm_rank = 0;
+    if (r != ncclSuccess) return fail(ctx, LEMSM_ERR_RCCL, std::string("ncclCommDestroy: ") + Rccl::get().GetErrorString(r));
+  }
+  return LEMSM_OK;
+}
+
+int lemsm_comm_info(const lemsm_ctx* ctx, int* nranks, int* rank) {
+  if (!ctx) return LEMSM_ERR_BAD_ARG;
+  if (nranks) *nranks = ctx->comm ? ctx->comm_size : 0;
+  if (rank) *rank = ctx->comm ? ctx->comm_rank : 0;
+  return LEMSM_OK;
+}
+
+int lemsm_msm_sharded_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, uint64_t out[12]) {
+  if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (!ctx->comm) return fail(ctx, LEMSM_ERR_BAD_ARG, "no communicator: call lemsm_comm_init on every rank first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Exchange ex{ctx->comm_size, ctx->comm_rank, false};
+  return msm_sharded_dispatch(ctx, curve, d_scalars, d_points, n, ex, out);
+}
+
+int lemsm_lhs_msm_sharded_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, uint8_t base,
+                                 uint64_t out_carry[12], uint64_t* out_carries, size_t* bad_index) {
+  if (!ctx || !out_carry) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
+  if (!ctx->comm) return fail(ctx, LEMSM_ERR_BAD_ARG, "no communicator: call lemsm_comm_init on every rank first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Exchange ex{ctx->comm_size, ctx->comm_rank, false};
+  return lhs_sharded_dispatch(ctx, curve, d_scalars, d_points, n, lp, ex, out_carry, out_carries, bad_index);
+}
+
+// one-GPU rehearsal of the sharded entries (tests): all `world` ranks' pipelines on this context, one after the other
+int lemsm_debug_msm_sharded_sim(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, int world, uint64_t out[12]) {
+  if (!ctx || !out || world < 1 || world > 64) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Exchange ex{world, 0, true};
+  return msm_sharded_dispatch(ctx, curve, d_scalars, d_points, n, ex, out);
+}
+int lemsm_debug_lhs_sharded_sim(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, uint8_t base, int world,
+                                uint64_t out_carry[12], uint64_t* out_carries, size_t* bad_index) {
+  if (!ctx || !out_carry || world < 1 || world > 256) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Exchange ex{world, 0, true};
+  return lhs_sharded_dispatch(ctx, curve, d_scalars, d_points, n, lp, ex, out_carry, out_carries, bad_index);
+}
+
+// ---- resident bases (halo2's bases are a fixed SRS: upload once, then only scalars cross PCIe) ------------------
+struct lemsm_bases { lemsm_ctx* ctx; int curve; size_t n; void* d_points; };
+
+int lemsm_bases_upload(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, size_t n, lemsm_bases** out) {
+  if (!ctx || !out || (n && !points_affine)) return LEMSM_ERR_BAD_ARG;
+  *out = nullptr;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, n ? n * 64 : 64);
+  if (e != hipSuccess) return fail(ctx, LEMSM_ERR_NOMEM, hipGetErrorString(e));
+  if (n) { e = hipMemcpy(d, points_affine, n * 64, hipMemcpyHostToDevice); if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, LEMSM_ERR_HIP, hipGetErrorString(e)); } }
+  *out = new lemsm_bases{ctx, curve, n, d};
+  return LEMSM_OK;
+}
+void lemsm_bases_free(lemsm_bases* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipFree(b->d_points);
+  delete b;
+}
+const void* lemsm_bases_device_ptr(const lemsm_bases* b) { return b ? b->d_points : nullptr; }
+
+// sum_i scalars[i] * bases[i] for the first n bases; scalars are host memory, uploaded slab by slab under the kernels
+int lemsm_msm_with_bases(lemsm_ctx* ctx, const lemsm_bases* bases, const uint8_t* scalars, size_t n, uint64_t out[12]) {
+  if (!ctx || !bases || !out || (n && !scalars)) return LEMSM_ERR_BAD_ARG;
+  if (bases->ctx != ctx) return fail(ctx, LEMSM_ERR_BAD_ARG, "bases belong to another context");
+  if (n > bases->n) return fail(ctx, LEMSM_ERR_LEN_MISMATCH, "more scalars than resident bases");
+  if (n == 0) { memset(out, 0, 96); return LEMSM_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = reserve(ctx, ctx->in_s, n * 32); if (rc) return rc;
+  HostStage hs{scalars, nullptr, (char*)ctx->in_s.p, (char*)bases->d_points};
+  ctx->host_stage = &hs;
+  rc = lemsm_msm_device(ctx, bases->curve, ctx->in_s.p, bases->d_points, n, out);
+  ctx->host_stage = nullptr;
+  return rc;
+}
+
+// ---- one process, all GPUs of the node: what a Rust host binds -----------------------------
+// One context + one communicator per device, one host thread per device for the duration of a call.
+struct lemsm_node {
+  std::vector<lemsm_ctx*> ctx;
+  std::vector<void*> d_scalars, d_points;   // per device: replicated inputs (bases resident across calls)
+  std::vector<size_t> cap_s;
+  int curve = -1; size_t n_bases = 0;
+  std::string last_error;
+};
+
+int lemsm_node_create(const int* devices, int ndev, lemsm_node** out) {
+  if (!out || ndev < 1 || ndev > 64) return LEMSM_ERR_BAD_ARG;
+  *out = nullptr;
+  lemsm_node* nd = new lemsm_node();
+  int rc = LEMSM_OK;
+  for (int i = 0; i < ndev && !rc; i++) {
+    lemsm_ctx* c = nullptr;
+    rc = lemsm_create(devices ? devices[i] : i, &c);
+    if (!rc) nd->ctx.push_back(c);
+  }
+  uint8_t id[LEMSM_COMM_ID_BYTES];
+  if (!rc) rc = lemsm_comm_unique_id(id);
+  if (!rc) {   // ncclCommInitRank blocks until every rank has joined: one thread per rank
+    std::vector<int> rcs(ndev, 0);
+    std::vector<std::thread> th;
+    for (int i = 0; i < ndev; i++) th.emplace_back([&, i] { rcs[i] = lemsm_comm_init(nd->ctx[i], id, ndev, i); });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < ndev; i++) if (rcs[i] && !rc) rc = rcs[i];
+  }
+  if (rc) { lemsm_node_destroy(nd); return rc; }
+  nd->d_scalars.assign(ndev, nullptr); nd->d_points.assign(ndev, nullptr); nd->cap_s.assign(ndev, 0);
+  *out = nd;
+  return LEMSM_OK;
+}
+
+void lemsm_node_destroy(lemsm_node* nd) {
+  if (!nd) return;
+  for (size_t i = 0; i < nd->ctx.size(); i++) {
+    (void)hipSetDevice(nd->ctx[i]->device);
+    if (i < nd->d_scalars.size() && nd->d_scalars[i]) (void)hipFree(nd->d_scalars[i]);
+    if (i < nd->d_points.size() && nd->d_points[i]) (void)hipFree(nd->d_points[i]);
+    (void)lemsm_comm_destroy(nd->ctx[i]);
+    lemsm_destroy(nd->ctx[i]);
+  }
+  delete nd;
+}
+
+int lemsm_node_size(const lemsm_node* nd) { return nd ? (int)nd->ctx.size() : 0; }
+lemsm_ctx* lemsm_node_ctx(lemsm_node* nd, int i) { return (nd && i >= 0 && i < (int)nd->ctx.size()) ? nd->ctx[i] : nullptr; }
+const char* lemsm_node_last_error(const lemsm_node* nd) { return nd ? nd->last_error.c_str() : "null node"; }
+
+// runs fn(rank) on one thread per device and returns the first non-zero status (its message kept in the node)
+static int node_parallel(lemsm_node* nd, const std::function<int(int)>& fn) {
+  const int G = (int)nd->ctx.size();
+  std::vector<int> rcs(G, 0);
+  if (G == 1) rcs[0] = fn(0);
+  else {
+    std::vector<std::thread> th;
+    for (int i = 0; i < G; i++) th.emplace_back([&, i] { rcs[i] = fn(i); });
+    for (auto& t : th) t.join();
+  }
+  for (int i = 0; i < G; i++) if (rcs[i]) { nd->last_error = "rank " + std::to_string(i) + ": " + nd->ctx[i]->last_error; return rcs[i]; }
+  return LEMSM_OK;
+}
+
+// Bases (affine, n x 8 limbs) replicated into every device's HBM once; they stay resident across lemsm_node_* calls.
+int lemsm_node_set_bases(lemsm_node* nd, int curve, const uint64_t* points_affine, size_t n) {
+  if (!nd || (n && !points_affine)) return LEMSM_ERR_BAD_ARG;
+  if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return LEMSM_ERR_BAD_CURVE;
+  int rc = node_parallel(nd, [&](int i) -> int {
+    lemsm_ctx* c = nd->ctx[i];
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nd->d_points[i]) { HIPCHK(c, hipFree(nd->d_points[i])); nd->d_points[i] = nullptr; }
+    hipError_t e = hipMalloc(&nd->d_points[i], n ? n * 64 : 64);
+    if (e != hipSuccess) return fail(c, LEMSM_ERR_NOMEM, hipGetErrorString(e));
+    if (n) HIPCHK(c, hipMemcpy(nd->d_points[i], points_affine, n * 64, hipMemcpyHostToDevice));
+    return LEMSM_OK;
+  });
+  if (rc) return rc;
+  nd->curve = curve; nd->n_bases = n;
+  return LEMSM_OK;
+}
+
+static int node_stage_scalars(lemsm_node* nd, int i, const uint8_t* scalars, size_t n) {
+  lemsm_ctx* c = nd->ctx[i];
+  HIPCHK(c, hipSetDevice(c->device));
+  if (nd->cap_s[i] < n * 32) {
+    if (nd->d_scalars[i]) { HIPCHK(c, hipFree(nd->d_scalars[i])); nd->d_scalars[i] = nullptr; nd->cap_s[i] = 0; }
+    hipError_t e = hipMalloc(&nd->d_scalars[i], n * 32 + 64);
+    if (e != hipSuccess) return fail(c, LEMSM_ERR_NOMEM, hipGetErrorString(e));
+    nd->cap_s[i] = n * 32 + 64;
+  }
+  if (n) HIPCHK(c, hipMemcpy(nd->d_scalars[i], scalars, n * 32, hipMemcpyHostToDevice));
+  return LEMSM_OK;
+}
+
+// best_multiexp over the node: scalars (host) are replicated to every GPU, each GPU accumulates its Pippenger windows,
+// one RCCL all-gather of the raw window records, every GPU combines; out = rank 0's result (all ranks' agree).
+int lemsm_node_msm(lemsm_node* nd, const uint8_t* scalars, size_t n, uint64_t out[12]) {
+  if (!nd || !out || (n && !scalars)) return LEMSM_ERR_BAD_ARG;
+  if (nd->curve < 0) { nd->last_error = "lemsm_node_set_bases first"; return LEMSM_ERR_BAD_ARG; }
+  if (n > nd->n_bases) { nd->last_error = "more scalars than resident bases"; return LEMSM_ERR_LEN_MISMATCH; }
+  std::vector<uint64_t> outs((size_t)nd->ctx.size() * 12);
+  int rc = node_parallel(nd, [&](int i) -> int {
+    int r = node_stage_scalars(nd, i, scalars, n); if (r) return r;
+    return lemsm_msm_sharded_device(nd->ctx[i], nd->curve, nd->d_scalars[i], nd->d_points[i], n, outs.data() + 12 * (size_t)i);
+  });
+  if (rc) return rc;
+  memcpy(out, outs.data(), 96);
+  return LEMSM_OK;
+}
+
+// compute_lhs_witness MSM core over the node, digit positions sharded; bases as set by lemsm_node_set_bases (affine).
+int lemsm_node_lhs_msm(lemsm_node* nd, const uint8_t* scalars, size_t n, uint8_t base, uint64_t out_carry[12], uint64_t* out_carries,
+                       size_t* bad_index) {
+  if (!nd || !out_carry || (n && !scalars)) return LEMSM_ERR_BAD_ARG;
+  if (nd->curve < 0) { nd->last_error = "lemsm_node_set_bases first"; return LEMSM_ERR_BAD_ARG; }
+  if (n != nd->n_bases) { nd->last_error = "incompatible amount of coefficients"; return LEMSM_ERR_LEN_MISMATCH; }
+  uint32_t d = 0; int rc = lemsm_num_digits(nd->curve, base, &d); if (rc || base < 3) return LEMSM_ERR_BAD_BASE;
+  const size_t G = nd->ctx.size();
+  std::vector<uint64_t> carry(G * 12), carries(out_carries ? G * 12 * d : 0);
+  std::vector<size_t> bad(G, 0);
+  rc = node_parallel(nd, [&](int i) -> int {
+    int r = node_stage_scalars(nd, i, scalars, n); if (r) return r;
+    return lemsm_lhs_msm_sharded_device(nd->ctx[i], nd->curve, nd->d_scalars[i], nd->d_points[i], n, base, carry.data() + 12 * (size_t)i,
+                                        out_carries ? carries.data() + (size_t)i * 12 * d : nullptr, &bad[i]);
+  });
+  if (rc) { if (bad_index) *bad_index = bad[0]; return rc; }
+  memcpy(out_carry, carry.data(), 96);
+  if (out_carries) memcpy(out_carries, carries.data(), (size_t)12 * d * 8);
+  return LEMSM_OK;
 }
 
 int lemsm_precompute_multiplicities(lemsm_ctx* ctx, int curve, const uint64_t* pts_jac, size_t n, uint8_t base, uint64_t* out) {

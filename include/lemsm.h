@@ -62,7 +62,8 @@ enum lemsm_status {
   LEMSM_ERR_HIP = 5,
   LEMSM_ERR_BAD_ARG = 6,
   LEMSM_ERR_NOMEM = 7,
-  LEMSM_ERR_TOO_MANY_DIGITS = 8
+  LEMSM_ERR_TOO_MANY_DIGITS = 8,
+  LEMSM_ERR_RCCL = 9
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -123,6 +124,54 @@ int lemsm_msm_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars,
                              uint32_t win_end, uint8_t* out_partials /* (win_end-win_begin) records */);
 int lemsm_msm_combine(const lemsm_ctx* ctx, int curve, size_t n, const uint8_t* partials_all_windows,
                       uint64_t out_jacobian[12]);
+
+/* ---- multi-GPU: Pippenger-window sharding over the GPUs of one node, RCCL over xGMI ------ */
+/* The reference has no distributed code (its parallelism is Rayon inside best_multiexp, called at
+   src/argument_witness_calc.rs:144); these entries are what its Rust host binds to use more than one GPU.
+   Rank r of G owns windows [W r / G, W (r+1) / G) (digit positions on the lhs path) over ALL points, which every rank
+   holds in its own HBM; the ranks exchange the raw per-window records with ONE ncclAllGather straight from device
+   memory (EC addition is not an RCCL reduction operator) and every rank combines, so every rank returns the
+   same group element.  RCCL is bound at run time (dlopen of librccl.so.1; override with LEMSM_RCCL_LIB): the
+   single-GPU entries never need it, a failure to load it is LEMSM_ERR_RCCL here.
+   Two ways in:
+     one process per GPU   lemsm_comm_unique_id on rank 0, the 128 bytes sent to the other ranks by the host's own
+                           means, lemsm_comm_init on every rank (collective), then lemsm_*_sharded_device (collective);
+     one process, N GPUs   lemsm_node_*: contexts, communicators and one host thread per GPU inside the library. */
+#define LEMSM_COMM_ID_BYTES 128
+int lemsm_comm_unique_id(uint8_t id[LEMSM_COMM_ID_BYTES]);
+int lemsm_comm_init(lemsm_ctx* ctx, const uint8_t id[LEMSM_COMM_ID_BYTES], int nranks, int rank);
+int lemsm_comm_destroy(lemsm_ctx* ctx);
+int lemsm_comm_info(const lemsm_ctx* ctx, int* nranks, int* rank);   /* nranks = 0: no communicator */
+/* Collective over the context's communicator; inputs resident on every rank.  With automatic window width a
+   sharded call uses 16-bit windows from 2^24 points (16 windows split evenly over 2/4/8 ranks). */
+int lemsm_msm_sharded_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine, size_t n,
+                             uint64_t out_jacobian[12]);
+int lemsm_lhs_msm_sharded_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine, size_t n,
+                                 uint8_t base, uint64_t out_carry[12], uint64_t* out_carries, size_t* bad_index);
+
+typedef struct lemsm_node lemsm_node;
+/* devices == NULL: devices 0..ndev-1 */
+int lemsm_node_create(const int* devices, int ndev, lemsm_node** out);
+void lemsm_node_destroy(lemsm_node* node);
+int lemsm_node_size(const lemsm_node* node);
+lemsm_ctx* lemsm_node_ctx(lemsm_node* node, int i);
+const char* lemsm_node_last_error(const lemsm_node* node);
+/* bases: n affine points (host), replicated into every GPU once and kept resident (halo2's bases are a fixed SRS) */
+int lemsm_node_set_bases(lemsm_node* node, int curve, const uint64_t* points_affine, size_t n);
+/* best_multiexp(scalars, bases[..n]) over the node */
+int lemsm_node_msm(lemsm_node* node, const uint8_t* scalars, size_t n, uint64_t out_jacobian[12]);
+/* compute_lhs_witness MSM core over the node (n must equal the number of resident bases, :88) */
+int lemsm_node_lhs_msm(lemsm_node* node, const uint8_t* scalars, size_t n, uint8_t base, uint64_t out_carry[12],
+                       uint64_t* out_carries, size_t* bad_index);
+
+/* ---- resident bases on one GPU ------------------------------------------------------- */
+/* best_multiexp(&scalars, &pts_aff) (src/argument_witness_calc.rs:144) with pts_aff uploaded once: later calls move
+   only the scalars over PCIe, slab by slab under the kernels of the previous slab. */
+typedef struct lemsm_bases lemsm_bases;
+int lemsm_bases_upload(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, size_t n, lemsm_bases** out);
+void lemsm_bases_free(lemsm_bases* bases);
+const void* lemsm_bases_device_ptr(const lemsm_bases* bases);
+int lemsm_msm_with_bases(lemsm_ctx* ctx, const lemsm_bases* bases, const uint8_t* scalars, size_t n, uint64_t out_jacobian[12]);
 
 /* ---- negabase decomposition ---------------------------------------------------------- */
 int lemsm_num_digits(int curve, uint8_t base, uint32_t* d);
@@ -191,6 +240,13 @@ int lemsm_debug_montmul(lemsm_ctx* ctx, int curve, const uint64_t* a, const uint
 int lemsm_debug_fieldop(lemsm_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int lemsm_debug_pointop(lemsm_ctx* ctx, int curve, int op, const uint64_t* acc_xyzz, const uint64_t* q,
                         uint64_t* out_xyzz, size_t n);
+/* One-GPU rehearsal of the sharded entries: the pipelines of all `world` ranks run one after the other on this
+   context and their record areas are placed where the all-gather would put them; everything but the ncclAllGather
+   call itself is the code of lemsm_*_sharded_device. */
+int lemsm_debug_msm_sharded_sim(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine, size_t n,
+                                int world, uint64_t out_jacobian[12]);
+int lemsm_debug_lhs_sharded_sim(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine, size_t n,
+                                uint8_t base, int world, uint64_t out_carry[12], uint64_t* out_carries, size_t* bad_index);
 
 #ifdef __cplusplus
 }

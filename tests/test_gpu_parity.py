@@ -673,6 +673,8 @@ def test_msm_bn254_2p26_window_sharded_x8(ctx):
     finally:
         ctx.set_option("window_bits", 0)
     assert canon(curve, out) == exp
+    # the same through the C ABI's sharded entry (raw device records, the exchange simulated on one GPU)
+    assert canon(curve, ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, 8)) == exp
     ds.free(); dp.free()
 
 
@@ -735,3 +737,94 @@ def test_negbase_truncation_is_counted(ctx):
     digs = ctx.negbase_decompose_batch(sc, 16, 5)
     assert ctx.last_truncated_count() == 2
     assert digs.shape == (4, 5)
+
+
+# ------------------------------------------------------------------ multi-GPU entries of the C ABI, rehearsed on one GPU
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_msm_sharded_sim_matches_oracle(fctx, curve, world):
+    """lemsm_debug_msm_sharded_sim = the code of lemsm_msm_sharded_device with the ranks' pipelines run one after the
+    other and their raw record areas placed where the all-gather puts them (uneven window ranges at world 3)"""
+    ctx = fctx
+    n = 3000
+    pts = cref.gen_points(curve.cid, 1001, n); sc = cref.gen_scalars(curve.cid, 1002 + world, n)
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    exp = canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    assert canon(curve, ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, world)) == exp
+
+
+def test_msm_sharded_sim_multi_slab_and_more_ranks_than_windows(ctx):
+    """several slabs per rank (their records are summed after the exchange) and world > W (ranks with no window)"""
+    curve = pyref.BN254_G1
+    n = 3 * 4096 + 77
+    pts = cref.gen_points(curve.cid, 1011, n); sc = cref.gen_scalars(curve.cid, 1012, n)
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    exp = canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    ctx.set_option("slab_bits", 12)
+    try:
+        assert canon(curve, ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, 4)) == exp
+        W, _ = ctx.msm_plan(curve.cid, 4096)
+        assert canon(curve, ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, W + 3)) == exp
+    finally:
+        ctx.set_option("slab_bits", 0)
+    assert canon(curve, ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, 0, 4)) == bytes(64)
+
+
+@pytest.mark.parametrize("world,base", [(1, 5), (2, 16), (8, 16), (40, 16), (3, 255)])
+def test_lhs_sharded_sim_matches_oracle(fctx, world, base):
+    """digit-position sharding of the compute_lhs_witness core; world 40 > d = 33 leaves ranks without a position"""
+    ctx = fctx
+    curve = pyref.GRUMPKIN
+    n = 1500
+    pts = cref.gen_points(curve.cid, 1021, n); sc = cref.gen_scalars(curve.cid, 1022 + world, n, half=True)
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    ecarry, ecarries = cref.lhs_msm(curve.cid, sc, cref.aff_to_jac(curve.cid, pts), base)
+    carry, carries = ctx.debug_lhs_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, base, world)
+    assert canon(curve, carry) == canon(curve, ecarry)
+    for i in range(carries.shape[0]):
+        assert canon(curve, carries[i]) == canon(curve, ecarries[i]), i
+
+
+def test_lhs_sharded_sim_reports_out_of_range_scalar(ctx):
+    curve = pyref.GRUMPKIN
+    n = 300
+    pts = cref.gen_points(curve.cid, 1031, n); sc = cref.gen_scalars(curve.cid, 1032, n, half=True)
+    sc[123] = np.frombuffer((math.isqrt(curve.order) + 2).to_bytes(32, "little"), np.uint8)
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    with pytest.raises(api.ScalarOutOfRange) as ei:
+        ctx.debug_lhs_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, 16, 4)
+    assert ei.value.index == 123
+
+
+def test_msm_sharded_sim_2p24_x8_walk(ctx):
+    """the bench's N = 8 shape on one GPU (16-bit windows pinned by the sharded entry itself, 2 windows per rank)"""
+    curve = pyref.BN254_G1
+    n = 1 << 24
+    q = cref.gen_points(curve.cid, 1041, 1)[0]
+    dp = ctx.gen_walk(curve.cid, q, n)
+    sc = cref.gen_scalars(curve.cid, 1042, n)
+    ds = ctx.to_device(sc)
+    exp = canon(curve, cref.scalar_mul(curve.cid, cref.walk_dot(curve.cid, sc), q))
+    assert canon(curve, ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, 8)) == exp
+    ds.free(); dp.free()
+
+
+# ------------------------------------------------------------------ resident bases
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm_with_resident_bases(ctx, curve):
+    """lemsm_bases_upload + lemsm_msm_with_bases: bases uploaded once, scalars staged slab by slab; a prefix of the bases
+    may be used (n <= resident count), more scalars than bases is the reference's length assert (:88)"""
+    n = 20000
+    pts = cref.gen_points(curve.cid, 1051, n)
+    bases = ctx.bases_upload(curve.cid, pts)
+    ctx.set_option("host_slab_bits", 12)
+    try:
+        for m, seed in ((n, 1052), (4097, 1053), (1, 1054)):
+            sc = cref.gen_scalars(curve.cid, seed, m)
+            assert canon(curve, ctx.msm_with_bases(bases, sc)) == canon(curve, cref.best_multiexp(curve.cid, sc, pts[:m], 8)), m
+    finally:
+        ctx.set_option("host_slab_bits", 0)
+    assert canon(curve, ctx.msm_with_bases(bases, np.zeros((0, 32), np.uint8))) == bytes(64)
+    with pytest.raises(api.LengthMismatch):
+        ctx.msm_with_bases(bases, cref.gen_scalars(curve.cid, 1055, n + 1))
+    bases.free()

@@ -37,3 +37,45 @@ def test_rccl_single_rank_all_gather():
     env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(port)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
+
+
+CHILD_ABI = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+from halo2_liam_eagen_msm_amd import Context, Node, comm_unique_id
+from oracle import cref
+# (1) one process per GPU form: unique id -> comm_init -> collective entries, world 1
+ctx = Context(0)
+uid = comm_unique_id(); assert len(uid) == 128
+ctx.comm_init(uid, 1, 0); assert ctx.comm_info() == (1, 0)
+n = 5000
+pts = cref.gen_points(0, 71, n); sc = cref.gen_scalars(0, 72, n)
+ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+exp = cref.jac_to_canonical(0, cref.best_multiexp(0, sc, pts, 8))
+assert cref.jac_to_canonical(0, ctx.msm_sharded_device(0, ds.ptr, dp.ptr, n)) == exp
+assert cref.jac_to_canonical(0, ctx.msm_device(0, ds.ptr, dp.ptr, n)) == exp
+sch = cref.gen_scalars(0, 73, n, half=True); dsh = ctx.to_device(sch)
+ec, ecs = cref.lhs_msm(0, sch, cref.aff_to_jac(0, pts), 16)
+c, cs = ctx.lhs_msm_sharded_device(0, dsh.ptr, dp.ptr, n, 16)
+assert cref.jac_to_canonical(0, c) == cref.jac_to_canonical(0, ec)
+assert all(cref.jac_to_canonical(0, cs[i]) == cref.jac_to_canonical(0, ecs[i]) for i in range(cs.shape[0]))
+ctx.comm_destroy(); assert ctx.comm_info() == (0, 0)
+ctx.close()
+# (2) one process, N GPUs form (N = 1 here): contexts + communicators + threads inside the library
+node = Node(ndev=1); assert node.size == 1
+node.set_bases(0, pts)
+assert cref.jac_to_canonical(0, node.msm(sc)) == exp
+c, cs = node.lhs_msm(sch, 16)
+assert cref.jac_to_canonical(0, c) == cref.jac_to_canonical(0, ec)
+node.close()
+print("rccl abi ok")
+"""
+
+
+def test_rccl_behind_c_abi_world1():
+    """lemsm_comm_* / lemsm_*_sharded_device / lemsm_node_*: RCCL bound by dlopen inside liblemsm.so, communicator of
+    one rank (all a one-GPU box allows), ncclAllGather of the raw device records, results equal the oracle's"""
+    env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", CHILD_ABI, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl abi ok" in r.stdout, r.stdout + r.stderr
