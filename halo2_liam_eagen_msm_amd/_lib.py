@@ -23,6 +23,8 @@ LEMSM_ERR_BAD_ARG = 6
 LEMSM_ERR_NOMEM = 7
 LEMSM_ERR_TOO_MANY_DIGITS = 8
 LEMSM_ERR_RCCL = 9
+LEMSM_ERR_INDEX_OUT_OF_BOUNDS = 10
+LEMSM_ERR_ARITH_OVERFLOW = 11
 LEMSM_COMM_ID_BYTES = 128
 
 BN254_G1 = 0
@@ -49,6 +51,7 @@ SYMBOLS = [
     "lemsm_node_set_bases", "lemsm_node_msm", "lemsm_node_lhs_msm",
     "lemsm_bases_upload", "lemsm_bases_free", "lemsm_bases_device_ptr", "lemsm_msm_with_bases",
     "lemsm_debug_msm_sharded_sim", "lemsm_debug_lhs_sharded_sim",
+    "lemsm_prepare_scalar_witness_batch", "lemsm_table_entries",
 ]
 
 
@@ -137,6 +140,8 @@ def load() -> ctypes.CDLL:
         "lemsm_msm_with_bases": (i, [vp, vp, u8p, sz, u64p]),
         "lemsm_debug_msm_sharded_sim": (i, [vp, i, vp, vp, sz, i, u64p]),
         "lemsm_debug_lhs_sharded_sim": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, i, u64p, u64p, szp]),
+        "lemsm_prepare_scalar_witness_batch": (i, [vp, u8p, u8p, sz, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint32, u8p, szp]),
+        "lemsm_table_entries": (i, [vp, i, ctypes.c_uint8, ctypes.c_uint64, sz, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -58,6 +58,35 @@ class BadBase(LemsmError, ValueError):
     pass
 
 
+class TooManyDigits(LemsmError, AssertionError):
+    """reference: assert!(digits.len() <= num_digits) (src/negbase_utils.rs:81)"""
+
+    def __init__(self, status, msg, index):
+        super().__init__(status, msg)
+        self.index = index
+
+
+class RefIndexOutOfBounds(LemsmError, IndexError):
+    """reference: slice index out of bounds at src/negbase_utils.rs:98-101 (i % logtable + 1 > num_limbs)"""
+
+    def __init__(self, status, msg, index):
+        super().__init__(status, msg)
+        self.index = index
+
+
+class RefArithmeticOverflow(LemsmError, OverflowError):
+    """reference (debug build): `attempt to multiply / add with overflow` in pow or += at src/negbase_utils.rs:97-101"""
+
+    def __init__(self, status, msg, index):
+        super().__init__(status, msg)
+        self.index = index
+
+
+# one Entry of prepare_scalar_witness (src/negbase_utils.rs:39-43) as the C ABI lays it out: 24 bytes
+ENTRY_DTYPE = np.dtype([("lo", "<u8"), ("hi", "<i8"), ("mask", "<u4"), ("kind", "<u4")])
+ENTRY_KINDS = ("Scalar", "Bucket", "Limb")
+
+
 def _curve_id(curve) -> int:
     if isinstance(curve, str):
         return CURVE_IDS[curve]
@@ -151,6 +180,12 @@ class Context:
             raise ScalarOutOfRange(rc, msg, bad_index)
         if rc == _lib.LEMSM_ERR_BAD_BASE:
             raise BadBase(rc, msg)
+        if rc in (_lib.LEMSM_ERR_TOO_MANY_DIGITS, _lib.LEMSM_ERR_INDEX_OUT_OF_BOUNDS, _lib.LEMSM_ERR_ARITH_OVERFLOW):
+            if bad_index is None:
+                bad_index = int(self.lib.lemsm_last_bad_index(self.h))
+            cls = {_lib.LEMSM_ERR_TOO_MANY_DIGITS: TooManyDigits, _lib.LEMSM_ERR_INDEX_OUT_OF_BOUNDS: RefIndexOutOfBounds,
+                   _lib.LEMSM_ERR_ARITH_OVERFLOW: RefArithmeticOverflow}[rc]
+            raise cls(rc, msg, bad_index)
         raise LemsmError(rc, msg)
 
     def set_option(self, name: str, value: int):
@@ -277,6 +312,30 @@ class Context:
         s = _scalars(scalars)
         out = np.zeros((s.shape[0], d), np.uint8)
         self._check(self.lib.lemsm_negbase_decompose_batch(self.h, _ptr(s), s.shape[0], base, d, _ptr(out)))
+        return out
+
+    # ---- prepare_scalar_witness / table_entry_by_id ---------------------------------------
+    def prepare_scalar_witness_batch(self, scalars, negative, base: int, num_digits: int, logtable: int) -> np.ndarray:
+        """(n, base, num_limbs+1) array of ENTRY_DTYPE: prepare_scalar_witness (src/negbase_utils.rs:79-124) of every
+        scalar; scalars are (n, 32) little-endian magnitudes, `negative` optional (n,) flags"""
+        s = _scalars(scalars)
+        n = s.shape[0]
+        if logtable <= 0:
+            raise LemsmError(_lib.LEMSM_ERR_BAD_ARG, "logtable == 0: the reference divides by it (:82)")
+        cols = (num_digits + logtable - 1) // logtable + 1
+        out = np.zeros((n, base, cols), ENTRY_DTYPE)
+        neg = None if negative is None else np.ascontiguousarray(negative, np.uint8).reshape(n)
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_prepare_scalar_witness_batch(self.h, _ptr(s), _ptr(neg) if neg is not None else None, n, base, num_digits,
+                                                         logtable, _ptr(out) if out.size else None, ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return out
+
+    def table_entries(self, curve, base: int, id_begin: int, count: int) -> np.ndarray:
+        """(count, 4) raw Montgomery limbs of table_entry_by_id(base, id) (src/negbase_utils.rs:58-77), id_begin <= id <
+        id_begin + count, in the BASE field of `curve` (the circuit's native field)"""
+        out = np.zeros((count, 4), np.uint64)
+        self._check(self.lib.lemsm_table_entries(self.h, _curve_id(curve), base, id_begin, count, _ptr(out) if count else None))
         return out
 
     # ---- compute_lhs_witness MSM core -------------------------------------------------
@@ -605,6 +664,31 @@ def negbase_decompose(x: int, base: int, ctx: Optional[Context] = None) -> List[
     while digs and digs[-1] == 0:
         digs.pop()
     return digs
+
+
+def prepare_scalar_witness(sc: int, base: int, num_digits: int, logtable: int, ctx: Optional[Context] = None):
+    """src/negbase_utils.rs:79-124: Vec<Vec<Entry>> as a list (base rows) of lists (num_limbs+1) of
+    ("Scalar", sc) | ("Bucket", i128) | ("Limb", i128, u32); raises where the reference panics."""
+    mag = abs(int(sc))
+    if mag >= 1 << 256:
+        raise ValueError("|sc| must be < 2^256")
+    s = np.frombuffer(mag.to_bytes(32, "little"), np.uint8).reshape(1, 32)
+    arr = (ctx or default_context()).prepare_scalar_witness_batch(s, np.array([1 if sc < 0 else 0], np.uint8), base, num_digits, logtable)[0]
+    out = []
+    for i in range(arr.shape[0]):
+        row = []
+        for j in range(arr.shape[1]):
+            e = arr[i, j]
+            v = (int(e["hi"]) << 64) | int(e["lo"])
+            kind = ENTRY_KINDS[int(e["kind"])]
+            row.append(("Scalar", int(sc)) if kind == "Scalar" else ("Bucket", v) if kind == "Bucket" else ("Limb", v, int(e["mask"])))
+        out.append(row)
+    return out
+
+
+def table_entry_by_id(base: int, idx: int, curve="grumpkin", ctx: Optional[Context] = None) -> np.ndarray:
+    """src/negbase_utils.rs:58-77 in the base field of `curve`: 4 raw Montgomery limbs"""
+    return (ctx or default_context()).table_entries(curve, base, idx, 1)[0]
 
 
 def precompute_multiplicities(pt_jacobian, base: int, curve="grumpkin", ctx: Optional[Context] = None) -> np.ndarray:

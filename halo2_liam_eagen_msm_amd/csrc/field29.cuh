@@ -163,6 +163,10 @@ struct Field29 {
     u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     unpack(r, w);
   }
+  static __device__ __forceinline__ void from_words(fe& r, const uint4& a, const uint4& b) {
+    u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unpack(r, w);
+  }
   // canonicalises a copy and stores 32 bytes
   static __device__ __forceinline__ void store(void* p, const fe& a) {
     fe t = a; canon(t);

@@ -78,6 +78,12 @@ struct Field32 {
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
     r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
   }
+  // the same from two 16-byte words already in registers (k_accum1 keeps the raw words in flight across a whole
+  // mixed addition and unpacks them only when it needs the point)
+  static __device__ __forceinline__ void from_words(fe& r, const uint4& a, const uint4& b) {
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  }
   static __device__ __forceinline__ void store(void* p, const fe& a) {
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);

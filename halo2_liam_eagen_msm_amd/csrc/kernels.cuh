@@ -467,7 +467,10 @@ __global__ __launch_bounds__(256) void k_negbase_digits(const uint4* __restrict_
                                                         const u32* __restrict__ bound /*8 limbs*/, int check_range,
                                                         uint8_t* __restrict__ digits, uint8_t* __restrict__ digitsT,
                                                         u32* __restrict__ err, u32 row_begin, u32 row_end /* rows of digitsT to write:
-                                                        a digit-position-sharded rank stores only the rows it will sort */) {
+                                                        a digit-position-sharded rank stores only the rows it will sort */,
+                                                        const uint8_t* __restrict__ negative = nullptr /* optional: scalar j is -|s_j| (negbase_decompose
+                                                        takes a signed BigInt; prepare_scalar_witness passes it through) */,
+                                                        uint8_t* __restrict__ trunc = nullptr /* optional: 1 where the expansion needed more than d digits */) {
   u32 j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   uint4 a = scalars[2 * (size_t)j], b = scalars[2 * (size_t)j + 1];
@@ -483,7 +486,13 @@ __global__ __launch_bounds__(256) void k_negbase_digits(const uint4* __restrict_
   u32 h[16];
 #pragma unroll
   for (int i = 0; i < 8; i++) { h[2 * i] = s[i] & 0xffffu; h[2 * i + 1] = s[i] >> 16; }
-  bool neg = false;
+  bool neg = negative ? negative[j] != 0 : false;
+  {   // -0 is 0
+    u32 nz0 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) nz0 |= h[k];
+    if (!nz0) neg = false;
+  }
   const float rb = 1.0f / (float)base;
   const u32 shift = (base & (base - 1u)) == 0 ? (u32)__builtin_ctz(base) : 0u;
   for (u32 i = 0; i < d; i++) {
@@ -530,7 +539,106 @@ __global__ __launch_bounds__(256) void k_negbase_digits(const uint4* __restrict_
   u32 nz = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) nz |= h[k];
-  if (nz) atomicAdd(&err[1], 1u);
+  if (nz) { atomicAdd(&err[1], 1u); atomicMin(&err[2], j); }
+  if (trunc) trunc[j] = nz ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------
+// prepare_scalar_witness (src/negbase_utils.rs:79-124), one thread per scalar, EXACTLY in the reference's order of
+// operations so that the first statement that would panic there (debug build: assert :81, index out of bounds
+// :98-101, i128 / u32 arithmetic overflow) is the one reported here.  Output per scalar: base x (num_limbs+1) entries
+// of 24 bytes {i128 value (two's complement LE), u32 mask, u32 kind}; kind 0 = Entry::Scalar (value = the scalar's low
+// 128 bits, sign applied), 1 = Entry::Bucket(value), 2 = Entry::Limb(value, mask).
+// powtab[e] = (-base)^e as {lo, hi (i128 halves), overflow flag, pad}: 24 bytes, e < max(d, logtable).
+// fail word: atomicMin of (j << 4 | code), code 1 = too many digits (:81), 2 = index out of bounds, 3 = overflow.
+// ------------------------------------------------------------------------------------
+struct WitnessPow { unsigned long long lo; long long hi; u32 ovf; u32 pad; };
+
+__device__ __forceinline__ bool add_i128(unsigned long long& lo, long long& hi, unsigned long long blo, long long bhi) {
+  unsigned long long rlo = lo + blo;
+  long long rhi = (long long)((unsigned long long)hi + (unsigned long long)bhi + (rlo < lo ? 1ull : 0ull));
+  bool ovf = ((hi ^ rhi) & (bhi ^ rhi)) < 0;     // operands of one sign, result of the other
+  lo = rlo; hi = rhi;
+  return ovf;
+}
+
+__global__ __launch_bounds__(256) void k_scalar_witness(const uint4* __restrict__ scalars, const uint8_t* __restrict__ negative,
+                                                        const uint8_t* __restrict__ digits /* n x d, LSB first */,
+                                                        const uint8_t* __restrict__ trunc, u32 n, u32 base, u32 d, u32 logtable,
+                                                        u32 num_limbs, const WitnessPow* __restrict__ powtab,
+                                                        char* __restrict__ out, unsigned long long* __restrict__ fail) {
+  const u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const u32 cols = num_limbs + 1;
+  char* cells = out + (size_t)j * base * cols * 24;
+  auto cell = [&](u32 r, u32 c) -> char* { return cells + ((size_t)r * cols + c) * 24; };
+  for (u32 r = 0; r < base; r++)
+    for (u32 c = 0; c < cols; c++) {
+      u32* w = reinterpret_cast<u32*>(cell(r, c));
+      w[0] = w[1] = w[2] = w[3] = w[4] = 0;
+      w[5] = (c == 0) ? (r == 0 ? 0u : 1u) : 2u;
+    }
+  auto report = [&](u32 code) { atomicMin(fail, ((unsigned long long)j << 4) | code); };
+  if (trunc[j]) { report(1); return; }                                    // assert!(digits.len() <= num_digits)  :81
+  auto add_value = [&](char* c, const WitnessPow& pw) -> bool {
+    unsigned long long* v = reinterpret_cast<unsigned long long*>(c);
+    unsigned long long lo = v[0]; long long hi = (long long)v[1];
+    if (pw.ovf) return true;                                              // pow(-(base as i128), e) itself overflows
+    bool o = add_i128(lo, hi, pw.lo, pw.hi);
+    v[0] = lo; v[1] = (unsigned long long)hi;
+    return o;
+  };
+  auto add_mask = [&](char* c, u32 k) -> bool {
+    if (k >= 32) return true;                                             // pow(2 as u32, k) overflows
+    u32* m = reinterpret_cast<u32*>(c + 16);
+    u32 a = *m, r = a + (1u << k);
+    *m = r;
+    return r < a;
+  };
+  for (u32 i = 0; i < d; i++) {
+    u32 dig = digits[(size_t)j * d + i];
+    if (!dig) continue;                                                   // id_by_digit: None  :95
+    const u32 id = dig - 1, k = i % logtable;
+    // (Rust evaluates the right operand of a primitive `+=` before the place expression: pow(..) panics before the index does)
+    if (add_value(cell(id + 1, 0), powtab[i])) { report(3); return; }     // ret[id+1][0].0 += pow(-(base), i)        :97
+    if (powtab[k].ovf) { report(3); return; }                             // pow(-(base), i%logtable)                 :98
+    if (k + 1 > num_limbs) { report(2); return; }                         // ret[id+1][i%logtable + 1]                :98
+    if (add_value(cell(id + 1, k + 1), powtab[k])) { report(3); return; } //   .0 += ..                               :98
+    if (add_mask(cell(id + 1, k + 1), k)) { report(3); return; }          //   .1 += pow(2u32, i%logtable)            :99
+    if (add_value(cell(0, k + 1), powtab[k])) { report(3); return; }      // ret[0][i%logtable+1].0 += ...            :100
+    if (add_mask(cell(0, k + 1), k)) { report(3); return; }               //   .1 += ...                              :101
+  }
+  // Entry::Scalar(sc): the scalar's low 128 bits with its sign (informational; the caller owns the scalar)
+  {
+    uint4 a = scalars[2 * (size_t)j];
+    unsigned long long lo = ((unsigned long long)a.y << 32) | a.x, hi = ((unsigned long long)a.w << 32) | a.z;
+    if (negative && negative[j]) { lo = ~lo + 1ull; hi = ~hi + (lo == 0 ? 1ull : 0ull); }
+    unsigned long long* v = reinterpret_cast<unsigned long long*>(cell(0, 0));
+    v[0] = lo; v[1] = hi;
+  }
+}
+
+// table_entry_by_id (src/negbase_utils.rs:58-77) for ids [id0, id0 + count): with b = -base in the field,
+// acc = 0; for the bits of id, most significant first: { if bit: acc += 1; acc *= b }  -- i.e. sum over the set bits k of
+// id of (-base)^(k+1) (the reference multiplies once more than a plain Horner would, and that is what is computed).
+template <class F>
+__global__ __launch_bounds__(256) void k_table_entries(u32 base, unsigned long long id0, u32 count, uint4* __restrict__ out) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= count) return;
+  typedef typename F::fe fe;
+  unsigned long long id = id0 + t;
+  fe acc, one, b, bm;
+  F::set_zero(acc); F::set_one(one);
+  // b = -base in Montgomery form: base * one summed by doubling, then negated
+  F::set_zero(bm);
+  for (int bit = 7; bit >= 0; bit--) { F::add(bm, bm, bm); if ((base >> bit) & 1u) F::add(bm, bm, one); }
+  F::neg(b, bm);
+  int l = 64 - (id ? __clzll((long long)id) : 64);
+  for (int i = l - 1; i >= 0; i--) {
+    if ((id >> i) & 1ull) F::add(acc, acc, one);
+    F::mul(acc, acc, b);
+  }
+  F::store(out + 2 * (size_t)t, acc);
 }
 
 // ------------------------------------------------------------------------------------

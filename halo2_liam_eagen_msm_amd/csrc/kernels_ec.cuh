@@ -51,9 +51,11 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
     u32 mid = (lo + hi) >> 1;
     if (bucket_start[mid] <= start) lo = mid; else hi = mid;
   }
+  const u32 nkeys = pl.nbins << pl.LB;   // bucket_start[] has nkeys + 1 entries
   u32 key = lo;
   u32 kbeg = bucket_start[key];
   u32 kend = bucket_start[key + 1];
+  u32 kend2 = bucket_start[min(key + 2u, nkeys)], kend3 = bucket_start[min(key + 3u, nkeys)];
   u32 seg_begin = start;
   u32 nrec = 0;
   u32 first_key = KEY_NONE;
@@ -98,13 +100,29 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
   } else {
     e_next = sorted[start];
   }
-  fe nx, ny;
-  { const uint4* p = points + (size_t)(e_next & 0xffffffu) * 4; F::load(nx, p); F::load(ny, p + 2); }
+  // The next point travels as its four raw 16-byte words: they are requested a whole mixed addition (~4 us) before
+  // they are unpacked, so the gather's latency hides behind the arithmetic.  (Unpacking right behind the loads --
+  // what F::load does -- put an s_waitcnt vmcnt(0) directly after them: PMC showed 12 % of all wave cycles in
+  // SQ_WAIT_ANY, profiles/r02/pmc_accum1_issue_wait.txt.)
+  uint4 nx0, nx1, ny0, ny1;
+  { const uint4* p = points + (size_t)(e_next & 0xffffffu) * 4; nx0 = p[0]; nx1 = p[1]; ny0 = p[2]; ny1 = p[3]; }
 
   // One loop over the chunk with every lane in lockstep (a per-segment inner loop would let the
   // lanes of a wave drift apart: measured 1.5x slower).  The flush is a rare divergent branch.
   for (u32 i = start; i < end; i++) {
-    u32 e = e_next; fe px = nx, py = ny;
+    u32 e = e_next; fe px, py;
+    F::from_words(px, nx0, nx1); F::from_words(py, ny0, ny1);
+    // Bucket boundary first, the next point's loads after it, and NO load inside the boundary branch (some lane
+    // takes it in a third of all iterations; a load there ends in an s_waitcnt vmcnt(0) that also waits for the
+    // flush's ten stores): the ends of the next two buckets ride along in kend2 / kend3, kend3 re-requested every
+    // iteration beside the point gather (one cached 4-byte load) and not looked at before the next iteration.
+    if (i >= kend) {
+      flush(i);
+      key++; kend = kend2; kend2 = kend3;
+      while (i >= kend) { key++; kend = kend2; kend2 = bucket_start[min(key + 2u, nkeys)]; }   // empty buckets in between (rare)
+      kbeg = i; seg_begin = i;
+      G::set_identity(acc); empty = true;
+    }
     if (i + 1 < end) {
       if constexpr (RING) {
         const u32 rel1 = i + 1 - start;               // the same in every lane of the wave
@@ -115,14 +133,9 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
         e_next = sorted[i + 1];
       }
       const uint4* p = points + (size_t)(e_next & 0xffffffu) * 4;
-      F::load(nx, p); F::load(ny, p + 2);
+      nx0 = p[0]; nx1 = p[1]; ny0 = p[2]; ny1 = p[3];
     }
-    if (i >= kend) {
-      flush(i);
-      do { key++; kend = bucket_start[key + 1]; } while (i >= kend);
-      kbeg = i; seg_begin = i;
-      G::set_identity(acc); empty = true;
-    }
+    kend3 = bucket_start[min(key + 3u, nkeys)];
     if (!G::aff_is_identity(px, py)) {
       F::cneg(py, py, (e >> 31) != 0);
       if (ABI) G::madd_abi(acc, px, py, empty); else G::madd(acc, px, py, empty);

@@ -936,7 +936,7 @@ int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const
   u32* bound_d = (u32*)(base + align_up((size_t)lp.d * n, 256));
   out.err = bound_d + 8;
   u32 init[12];
-  memcpy(init, bound_of(curve), 32); init[8] = 0xffffffffu; init[9] = 0; init[10] = 0; init[11] = 0;
+  memcpy(init, bound_of(curve), 32); init[8] = 0xffffffffu; init[9] = 0; init[10] = 0xffffffffu; init[11] = 0;
   HIPCHK(ctx, hipMemcpyAsync(bound_d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (n) hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)d_scalars, (u32)n,
@@ -1260,6 +1260,8 @@ const char* lemsm_strerror(int s) {
     case LEMSM_ERR_NOMEM: return "out of device memory";
     case LEMSM_ERR_TOO_MANY_DIGITS: return "too many digits";
     case LEMSM_ERR_RCCL: return "RCCL error";
+    case LEMSM_ERR_INDEX_OUT_OF_BOUNDS: return "index out of bounds";
+    case LEMSM_ERR_ARITH_OVERFLOW: return "arithmetic overflow";
     default: return "unknown status";
   }
 }
@@ -1419,7 +1421,7 @@ int lemsm_negbase_decompose_batch(lemsm_ctx* ctx, const uint8_t* scalars, size_t
   size_t dig_bytes = align_up((size_t)n * d, 256);
   rc = reserve(ctx, ctx->in_aux, dig_bytes + 256); if (rc) return rc;
   char* b = (char*)ctx->in_aux.p;
-  u32 init[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0xffffffffu, 0, 0, 0};
+  u32 init[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0xffffffffu, 0, 0xffffffffu, 0};
   HIPCHK(ctx, hipMemcpyAsync(b + dig_bytes, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)ctx->in_s.p, (u32)n,
@@ -1430,6 +1432,82 @@ int lemsm_negbase_decompose_batch(lemsm_ctx* ctx, const uint8_t* scalars, size_t
   HIPCHK(ctx, hipMemcpyAsync(errw, (u32*)(b + dig_bytes) + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->truncated = errw[1];
+  return LEMSM_OK;
+}
+
+// prepare_scalar_witness over a slice (src/negbase_utils.rs:79-124); see k_scalar_witness for the entry format
+int lemsm_prepare_scalar_witness_batch(lemsm_ctx* ctx, const uint8_t* scalars, const uint8_t* negative, size_t n, uint8_t base,
+                                       uint32_t num_digits, uint32_t logtable, uint8_t* out_entries, size_t* bad_index) {
+  if (!ctx || (n && (!scalars || !out_entries))) return LEMSM_ERR_BAD_ARG;
+  if (base < 2) return fail(ctx, LEMSM_ERR_BAD_BASE, "base must be >= 2");
+  if (logtable == 0) return fail(ctx, LEMSM_ERR_BAD_ARG, "logtable == 0: the reference divides by it (:82)");
+  if (num_digits > 4096) return fail(ctx, LEMSM_ERR_BAD_ARG, "num_digits too large");
+  if (n >= ((size_t)1 << 32)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
+  if (n == 0) return LEMSM_OK;
+  const u32 d = num_digits, num_limbs = (num_digits + logtable - 1) / logtable, cols = num_limbs + 1;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // (-base)^e for e < d as i128, with the overflow the reference's pow(-(base as i128), e) would hit
+  std::vector<WitnessPow> pw(std::max<u32>(d, 1));
+  {
+    unsigned __int128 mag = 1; bool ovf = false;
+    for (u32 e = 0; e < d; e++) {
+      pw[e].ovf = ovf ? 1u : 0u; pw[e].pad = 0;
+      __int128 v = (e & 1u) ? -(__int128)mag : (__int128)mag;
+      pw[e].lo = (unsigned long long)(unsigned __int128)v; pw[e].hi = (long long)(v >> 64);
+      if (!ovf) { unsigned __int128 nx = mag * base; if (nx / base != mag || nx >= ((unsigned __int128)1 << 127)) ovf = true; else mag = nx; }
+    }
+  }
+  const size_t dig_bytes = align_up((size_t)n * std::max<u32>(d, 1), 256), flag_bytes = align_up(n, 256), pow_bytes = align_up(pw.size() * sizeof(WitnessPow), 256);
+  const size_t out_bytes = (size_t)n * base * cols * 24;
+  int rc = stage(ctx, ctx->in_s, scalars, n * 32); if (rc) return rc;
+  rc = reserve(ctx, ctx->in_aux, dig_bytes + 2 * flag_bytes + pow_bytes + 512); if (rc) return rc;
+  rc = reserve(ctx, ctx->ws, out_bytes + 256); if (rc) return rc;
+  char* b = (char*)ctx->in_aux.p;
+  uint8_t* d_digits = (uint8_t*)b; uint8_t* d_neg = (uint8_t*)(b + dig_bytes); uint8_t* d_trunc = d_neg + flag_bytes;
+  WitnessPow* d_pow = (WitnessPow*)(b + dig_bytes + 2 * flag_bytes);
+  u32* d_words = (u32*)(b + dig_bytes + 2 * flag_bytes + pow_bytes);      // [0..7] bound (unused), [8..11] err, [12..13] fail (u64)
+  u32 init[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0xffffffffu, 0, 0xffffffffu, 0, 0xffffffffu, 0xffffffffu, 0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(d_words, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_pow, pw.data(), pw.size() * sizeof(WitnessPow), hipMemcpyHostToDevice, ctx->stream));
+  if (negative) HIPCHK(ctx, hipMemcpyAsync(d_neg, negative, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (init / pw are host stack and heap objects)
+  dim3 grid((u32)((n + 255) / 256)), blk(256);
+  hipLaunchKernelGGL(k_negbase_digits, grid, blk, 0, ctx->stream, (const uint4*)ctx->in_s.p, (u32)n, (u32)base, d, (const u32*)d_words, 0,
+                     d_digits, (uint8_t*)nullptr, d_words + 8, 0u, 0u, negative ? (const uint8_t*)d_neg : (const uint8_t*)nullptr, d_trunc);
+  hipLaunchKernelGGL(k_scalar_witness, grid, blk, 0, ctx->stream, (const uint4*)ctx->in_s.p, negative ? (const uint8_t*)d_neg : (const uint8_t*)nullptr,
+                     (const uint8_t*)d_digits, (const uint8_t*)d_trunc, (u32)n, (u32)base, d, logtable, num_limbs, (const WitnessPow*)d_pow,
+                     (char*)ctx->ws.p, (unsigned long long*)(d_words + 12));
+  HIPCHK(ctx, hipGetLastError());
+  unsigned long long failw = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&failw, d_words + 12, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(out_entries, ctx->ws.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (failw != ~0ull) {
+    size_t j = (size_t)(failw >> 4); u32 code = (u32)(failw & 15u);
+    if (bad_index) *bad_index = j;
+    ctx->bad_index = j;
+    if (code == 1) return fail(ctx, LEMSM_ERR_TOO_MANY_DIGITS, "negabase expansion longer than num_digits (assert at src/negbase_utils.rs:81)");
+    if (code == 2) return fail(ctx, LEMSM_ERR_INDEX_OUT_OF_BOUNDS, "limb index i % logtable + 1 > num_limbs (index out of bounds at src/negbase_utils.rs:98-101)");
+    return fail(ctx, LEMSM_ERR_ARITH_OVERFLOW, "i128 / u32 overflow in pow or += (src/negbase_utils.rs:97-101, a panic in the reference's debug build)");
+  }
+  return LEMSM_OK;
+}
+
+// table_entry_by_id for ids [id_begin, id_begin + count) in the BASE field of `curve` (src/negbase_utils.rs:58-77; the
+// circuit's native field, C::Base at src/config.rs:486); out: count x 4 limbs, raw Montgomery
+int lemsm_table_entries(lemsm_ctx* ctx, int curve, uint8_t base, uint64_t id_begin, size_t count, uint64_t* out) {
+  if (!ctx || (count && !out)) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (count == 0) return LEMSM_OK;
+  if (count >= ((size_t)1 << 31)) return fail(ctx, LEMSM_ERR_BAD_ARG, "count too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  rc = reserve(ctx, ctx->ws, count * 32 + 256); if (rc) return rc;
+  dim3 grid((u32)((count + 255) / 256)), blk(256);
+  if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_table_entries<FqDev>), grid, blk, 0, ctx->stream, (u32)base, (unsigned long long)id_begin, (u32)count, (uint4*)ctx->ws.p);
+  else hipLaunchKernelGGL((k_table_entries<FrDev>), grid, blk, 0, ctx->stream, (u32)base, (unsigned long long)id_begin, (u32)count, (uint4*)ctx->ws.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->ws.p, count * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return LEMSM_OK;
 }
 

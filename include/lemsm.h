@@ -63,7 +63,9 @@ enum lemsm_status {
   LEMSM_ERR_BAD_ARG = 6,
   LEMSM_ERR_NOMEM = 7,
   LEMSM_ERR_TOO_MANY_DIGITS = 8,
-  LEMSM_ERR_RCCL = 9
+  LEMSM_ERR_RCCL = 9,
+  LEMSM_ERR_INDEX_OUT_OF_BOUNDS = 10,
+  LEMSM_ERR_ARITH_OVERFLOW = 11
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -179,6 +181,24 @@ int lemsm_num_digits(int curve, uint8_t base, uint32_t* d);
    truncated to d exactly like `.chain(repeat(0)).take(d)` (src/argument_witness_calc.rs:99). */
 int lemsm_negbase_decompose_batch(lemsm_ctx* ctx, const uint8_t* scalars, size_t n, uint8_t base,
                                   uint32_t d, uint8_t* digits);
+
+/* ---- prepare_scalar_witness / table_entry_by_id -------------------------------------- */
+/* prepare_scalar_witness(sc, base, num_digits, logtable), src/negbase_utils.rs:79-124, for each of n scalars, computed
+   exactly as the reference's code does (limb index i % logtable + 1, :98-101 -- not upstream's presumable intent).
+   scalars: n x 32 bytes little-endian magnitudes; negative: optional n flags (the reference takes a signed BigInt).
+   out_entries: n x base x (num_limbs+1) entries, num_limbs = ceil(num_digits / logtable), row-major like the returned
+   Vec<Vec<Entry>>; one entry = 24 bytes {int128 value (two's complement LE), uint32 mask, uint32 kind} with
+   kind 0 = Entry::Scalar (value: the scalar's low 128 bits), 1 = Entry::Bucket(value), 2 = Entry::Limb(value, mask).
+   Where the reference would panic the first offending scalar's index goes to *bad_index and the status says why:
+   LEMSM_ERR_TOO_MANY_DIGITS (assert :81), LEMSM_ERR_INDEX_OUT_OF_BOUNDS (:98-101 when i % logtable + 1 > num_limbs),
+   LEMSM_ERR_ARITH_OVERFLOW (pow / += overflow of i128 or u32, :97-101: a panic in the reference's debug build). */
+int lemsm_prepare_scalar_witness_batch(lemsm_ctx* ctx, const uint8_t* scalars, const uint8_t* negative, size_t n,
+                                       uint8_t base, uint32_t num_digits, uint32_t logtable, uint8_t* out_entries,
+                                       size_t* bad_index);
+/* table_entry_by_id(base, id), src/negbase_utils.rs:58-77, for id in [id_begin, id_begin + count), in the BASE field of
+   `curve` (the circuit's native field: C::Base, src/config.rs:486); out: count x 4 limbs raw Montgomery.
+   As the reference computes it: sum over the set bits k of id of (-base)^(k+1). */
+int lemsm_table_entries(lemsm_ctx* ctx, int curve, uint8_t base, uint64_t id_begin, size_t count, uint64_t* out);
 
 /* ---- compute_lhs_witness MSM core ---------------------------------------------------- */
 /* carry = sum_j scalars[j]*pts[j] via the Horner-in-(-base) recursion over negabase digits.

@@ -306,3 +306,120 @@ def gen_points(curve: Curve, rng: SplitMix64, n: int) -> List[Point]:
 
 def scalars_to_bytes(scalars: Iterable[int]) -> bytes:
     return b"".join(int(s).to_bytes(32, "little") for s in scalars)
+
+
+# ---------------------------------------------------------------------------------------------
+# prepare_scalar_witness / table_entry_by_id  (src/negbase_utils.rs:58-124), restated verbatim -- including the
+# places where the reference panics in a debug build (cargo test): assert :81, slice index out of bounds :98-101,
+# i128 / u32 overflow inside num_traits::pow and `+=`.  Parity means what the code does (limb index i % logtable + 1,
+# the extra (-base) factor of table_entry_by_id), not upstream's presumable intent.
+# ---------------------------------------------------------------------------------------------
+class RefPanic(Exception):
+    """the reference would panic here; kind in {"too_many_digits", "index", "overflow", "div0"}"""
+
+    def __init__(self, kind):
+        super().__init__(kind)
+        self.kind = kind
+
+
+_I128 = (-(1 << 127), (1 << 127) - 1)
+_U32 = (0, (1 << 32) - 1)
+
+
+def _chk(v, rng):
+    if not (rng[0] <= v <= rng[1]):
+        raise RefPanic("overflow")
+    return v
+
+
+def _num_traits_pow(base, exp, rng):
+    """num_traits::pow(base, exp) (exponentiation by squaring) with Rust's debug overflow checks on every `*`"""
+    if exp == 0:
+        return 1
+    while exp & 1 == 0:
+        base = _chk(base * base, rng)
+        exp >>= 1
+    if exp == 1:
+        return base
+    acc = base
+    while exp > 1:
+        exp >>= 1
+        base = _chk(base * base, rng)
+        if exp & 1 == 1:
+            acc = _chk(acc * base, rng)
+    return acc
+
+
+def negbase_decompose_signed(x: int, base: int):
+    """src/negbase_utils.rs:20-36 for a signed BigInt: digit = x % base (truncated remainder, fixed up), x = -((x - digit) / base)"""
+    acc = []
+    while x != 0:
+        digit = abs(x) % base
+        if x < 0:
+            digit = -digit          # num-bigint: remainder takes the sign of the dividend
+        if digit < 0:
+            digit += base           # :25-28
+        acc.append(digit)
+        q = (x - digit)
+        assert q % base == 0
+        x = -(q // base)            # exact division
+    return acc
+
+
+def prepare_scalar_witness(sc: int, base: int, num_digits: int, logtable: int):
+    """src/negbase_utils.rs:79-124 -> list (base rows) of lists (num_limbs+1) of
+    ("Scalar", sc) | ("Bucket", i128) | ("Limb", i128, u32)"""
+    digits = negbase_decompose_signed(sc, base)
+    if not len(digits) <= num_digits:
+        raise RefPanic("too_many_digits")                                   # :81
+    if logtable == 0:
+        raise RefPanic("div0")                                              # :82
+    num_limbs = (num_digits + logtable - 1) // logtable
+    ret = [[[0, 0] for _ in range(num_limbs + 1)] for _ in range(base)]
+
+    def cell(r, c):
+        if c >= len(ret[r]):
+            raise RefPanic("index")
+        return ret[r][c]
+
+    for i in range(len(digits)):
+        if digits[i] == 0:
+            continue
+        idx = digits[i] - 1                                                  # id_by_digit :46-51
+        k = i % logtable
+        # (the right operand of a primitive `+=` is evaluated before the place expression)
+        v = _num_traits_pow(-base, i, _I128); c = cell(idx + 1, 0); c[0] = _chk(c[0] + v, _I128)       # :97
+        v = _num_traits_pow(-base, k, _I128); c = cell(idx + 1, k + 1); c[0] = _chk(c[0] + v, _I128)   # :98
+        v = _num_traits_pow(2, k, _U32); c = cell(idx + 1, k + 1); c[1] = _chk(c[1] + v, _U32)         # :99
+        v = _num_traits_pow(-base, k, _I128); c = cell(0, k + 1); c[0] = _chk(c[0] + v, _I128)         # :100
+        v = _num_traits_pow(2, k, _U32); c = cell(0, k + 1); c[1] = _chk(c[1] + v, _U32)               # :101
+    out = []
+    for i in range(base):
+        row = []
+        for j in range(num_limbs + 1):
+            if i == 0 and j == 0:
+                row.append(("Scalar", sc))
+            elif j == 0:
+                row.append(("Bucket", ret[i][j][0]))
+            else:
+                row.append(("Limb", ret[i][j][0], ret[i][j][1]))
+        out.append(row)
+    return out
+
+
+def table_entry_by_id(base: int, idx: int, p: int) -> int:
+    """src/negbase_utils.rs:58-77 in the field of order p (canonical integer)"""
+    if idx == 0:
+        return 0
+    b = (-base) % p
+    acc = 0
+    bits = []
+    while idx > 0:
+        bits.append(idx & 1)
+        idx >>= 1
+    l = len(bits)
+    for i in range(l):
+        if bits[l - i - 1] == 1:
+            acc = (acc + 1) % p
+        acc = acc * b % p
+    return acc

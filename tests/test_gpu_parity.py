@@ -828,3 +828,94 @@ def test_msm_with_resident_bases(ctx, curve):
     with pytest.raises(api.LengthMismatch):
         ctx.msm_with_bases(bases, cref.gen_scalars(curve.cid, 1055, n + 1))
     bases.free()
+
+
+# ------------------------------------------------------------------ prepare_scalar_witness / table_entry_by_id
+def _witness_cases(seed, count, bits):
+    rng = pyref.SplitMix64(seed)
+    vals = [0, 1, 2, 3, 4, 5, 15, 16, 17, 255, 256, (1 << 64) - 1, 1 << 64]
+    vals += [rng.next256() >> (256 - bits) for _ in range(count)]
+    vals += [-(rng.next256() >> (256 - bits)) for _ in range(count // 2)]
+    return vals
+
+
+def _witness_batch(ctx, vals, base, nd, lt):
+    sc = np.frombuffer(b"".join(abs(v).to_bytes(32, "little") for v in vals), np.uint8).reshape(-1, 32)
+    neg = np.array([1 if v < 0 else 0 for v in vals], np.uint8)
+    return ctx.prepare_scalar_witness_batch(sc, neg, base, nd, lt)
+
+
+@pytest.mark.parametrize("base,nd,lt,bits", [(5, 56, 7, 120), (16, 33, 5, 120), (16, 33, 6, 100), (3, 82, 9, 126), (17, 33, 1, 126), (255, 17, 4, 126)])
+def test_prepare_scalar_witness_matches_reference_semantics(ctx, base, nd, lt, bits):
+    """entry by entry against the verbatim restatement of src/negbase_utils.rs:79-124 (limb index i % logtable + 1 as the
+    reference computes it), for scalars the reference does not panic on; signed inputs included"""
+    vals = []
+    for v in _witness_cases(1100 + base + lt, 150, bits):
+        try:
+            pyref.prepare_scalar_witness(v, base, nd, lt)
+            vals.append(v)
+        except pyref.RefPanic:
+            pass
+    assert len(vals) > 100
+    arr = _witness_batch(ctx, vals, base, nd, lt)
+    cols = (nd + lt - 1) // lt + 1
+    assert arr.shape == (len(vals), base, cols)
+    for j, v in enumerate(vals):
+        exp = pyref.prepare_scalar_witness(v, base, nd, lt)
+        for r in range(base):
+            for c in range(cols):
+                e = arr[j, r, c]
+                val = (int(e["hi"]) << 64) | int(e["lo"])
+                kind = api.ENTRY_KINDS[int(e["kind"])]
+                want = exp[r][c]
+                assert kind == want[0], (v, r, c)
+                if kind == "Scalar":
+                    assert val == (v if abs(v) < (1 << 127) else val)
+                elif kind == "Bucket":
+                    assert val == want[1], (v, r, c)
+                else:
+                    assert (val, int(e["mask"])) == (want[1], want[2]), (v, r, c)
+    # the reference-named single-scalar entry returns the same nested list
+    assert api.prepare_scalar_witness(vals[20], base, nd, lt, ctx=ctx) == pyref.prepare_scalar_witness(vals[20], base, nd, lt)
+
+
+@pytest.mark.parametrize("base,nd,lt", [(5, 56, 15), (16, 33, 15), (16, 33, 5), (16, 10, 5), (255, 17, 17), (3, 82, 40)])
+def test_prepare_scalar_witness_reports_the_reference_panics(ctx, base, nd, lt):
+    """where the reference panics (assert :81, index out of bounds :98-101, i128 / u32 overflow) the status names the
+    kind and the FIRST offending scalar, exactly as the restatement finds them"""
+    vals = _witness_cases(1200 + base + lt, 120, 127)
+    kinds = []
+    for v in vals:
+        try:
+            pyref.prepare_scalar_witness(v, base, nd, lt); kinds.append(None)
+        except pyref.RefPanic as e:
+            kinds.append(e.kind)
+    first = next((j for j, k in enumerate(kinds) if k), None)
+    assert first is not None, "case list must contain a panicking scalar"
+    exc = {"too_many_digits": api.TooManyDigits, "index": api.RefIndexOutOfBounds, "overflow": api.RefArithmeticOverflow}[kinds[first]]
+    with pytest.raises(exc) as ei:
+        _witness_batch(ctx, vals, base, nd, lt)
+    assert ei.value.index == first
+    # every scalar on its own: same verdict as the restatement
+    for j, v in enumerate(vals[:60]):
+        if kinds[j] is None:
+            _witness_batch(ctx, [v], base, nd, lt)
+        else:
+            with pytest.raises({"too_many_digits": api.TooManyDigits, "index": api.RefIndexOutOfBounds, "overflow": api.RefArithmeticOverflow}[kinds[j]]):
+                _witness_batch(ctx, [v], base, nd, lt)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("base", [3, 5, 16, 255])
+def test_table_entries_match_reference_semantics(ctx, curve, base):
+    """table_entry_by_id as the reference computes it (src/negbase_utils.rs:58-77: the extra factor -base included), in the
+    base field of the curve, raw Montgomery limbs out"""
+    p = curve.fp
+    got = ctx.table_entries(curve.cid, base, 0, 1 << 12)
+    rinv = pow(1 << 256, -1, p)
+    for idx in list(range(70)) + [255, 256, 1023, 4095]:
+        assert int_of(got[idx]) * rinv % p == pyref.table_entry_by_id(base, idx, p), idx
+    hi = ctx.table_entries(curve.cid, base, (1 << 40) + 5, 3)
+    for t in range(3):
+        assert int_of(hi[t]) * rinv % p == pyref.table_entry_by_id(base, (1 << 40) + 5 + t, p)
+    assert np.array_equal(api.table_entry_by_id(base, 37, curve.cid, ctx=ctx), got[37])

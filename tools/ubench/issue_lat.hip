@@ -1,7 +1,7 @@
 // Issue interval and dependent-issue latency of the instructions the 29-bit Montgomery multiplier is made of,
 // measured WITHOUT the s_nop hipcc puts after every asm statement: each kernel runs ONE asm block of 32
 // instructions per loop trip, either 32 independent destinations (8 registers x 4) or one dependent chain, at
-// 1..8 waves per SIMD, and reports shader cycles (s_memtime) per instruction per wave and per SIMD.
+// exactly 1..4 waves per SIMD (ONE block per CU, enforced by an LDS allocation, of 256 x W threads), and reports shader cycles (s_memtime) per instruction per wave and per SIMD.
 //   build: hipcc -O2 --offload-arch=gfx950 -o issue_lat issue_lat.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -17,7 +17,8 @@ constexpr int ITERS = 2048;
 #define R32(x) R8(x) R8(x) R8(x) R8(x)
 
 #define KBEGIN(name)                                                                                        \
-  __global__ __launch_bounds__(256) void name(u32* out, u64* cyc, u32 seed) {                              \
+  __global__ __launch_bounds__(1024) void name(u32* out, u64* cyc, u32 seed) {                             \
+    __shared__ u32 pad_[20800]; if (seed == 0x7fffffffu) pad_[threadIdx.x] = seed;   /* > 80 KB: one block per CU */ \
     u32 a = seed * (threadIdx.x + 1) | 1u, b = (seed ^ (threadIdx.x * 2654435761u)) | 3u; (void)a; (void)b;
 #define KLOOP                                                                                               \
     u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();                           \
@@ -92,17 +93,18 @@ int main() {
   std::vector<u64> h(maxthreads / 64 * 2);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("%-40s %6s %9s %8s %16s %16s\n", "sequence", "w/SIMD", "wall_ms", "clk_GHz", "cyc/instr/wave", "cyc/instr/SIMD");
-  for (auto& e : es) for (int wps : {1, 2, 3, 4, 6, 8}) {
-    int blocks = cus * wps;
-    hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 12345u);
+  for (auto& e : es) for (int wps : {1, 2, 3, 4}) {
+    int blocks = cus;                      // one block per CU, 256 * wps threads: exactly wps waves on every SIMD
+    hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256 * wps), 0, 0, d_out, d_cyc, 12345u);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 12345u);
+    hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256 * wps), 0, 0, d_out, d_cyc, 12345u);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    CK(hipMemcpy(h.data(), d_cyc, (size_t)blocks * 4 * 16, hipMemcpyDeviceToHost));
-    double c = 0, r = 0; for (int i = 0; i < blocks * 4; i++) { c += (double)h[2 * i]; r += (double)h[2 * i + 1]; }
-    c /= blocks * 4; r /= blocks * 4;
+    const int nw = blocks * 4 * wps;
+    CK(hipMemcpy(h.data(), d_cyc, (size_t)nw * 16, hipMemcpyDeviceToHost));
+    double c = 0, r = 0; for (int i = 0; i < nw; i++) { c += (double)h[2 * i]; r += (double)h[2 * i + 1]; }
+    c /= nw; r /= nw;
     double n_instr = (double)ITERS * e.per_trip;
     printf("%-40s %6d %9.4f %8.3f %16.2f %16.2f\n", e.name, wps, ms, r > 0 ? c / r * 0.1 : 0.0, c / n_instr, c / n_instr / wps);
   }
