@@ -856,7 +856,7 @@ def test_prepare_scalar_witness_matches_reference_semantics(ctx, base, nd, lt, b
             vals.append(v)
         except pyref.RefPanic:
             pass
-    assert len(vals) > 100
+    assert len(vals) > 60
     arr = _witness_batch(ctx, vals, base, nd, lt)
     cols = (nd + lt - 1) // lt + 1
     assert arr.shape == (len(vals), base, cols)
