@@ -9,5 +9,5 @@ from .api import (  # noqa: F401
     best_multiexp, compute_lhs_witness, compute_lhs_witness_inputs, negbase_decompose, precompute_multiplicities,
     jacobian_to_canonical, jacobian_sum, logb_ceil, order, num_digits, id_by_digit, digit_by_id,
     Bases, Node, comm_unique_id, prepare_scalar_witness, table_entry_by_id, TooManyDigits, RefIndexOutOfBounds,
-    RefArithmeticOverflow, ENTRY_DTYPE,
+    RefArithmeticOverflow, ENTRY_DTYPE, SumNotIdentity, compute_divisor_witness, compute_divisor_witness_partial,
 )

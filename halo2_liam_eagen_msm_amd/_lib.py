@@ -25,6 +25,7 @@ LEMSM_ERR_TOO_MANY_DIGITS = 8
 LEMSM_ERR_RCCL = 9
 LEMSM_ERR_INDEX_OUT_OF_BOUNDS = 10
 LEMSM_ERR_ARITH_OVERFLOW = 11
+LEMSM_ERR_SUM_NOT_IDENTITY = 12
 LEMSM_COMM_ID_BYTES = 128
 
 BN254_G1 = 0
@@ -52,6 +53,7 @@ SYMBOLS = [
     "lemsm_bases_upload", "lemsm_bases_free", "lemsm_bases_device_ptr", "lemsm_msm_with_bases",
     "lemsm_debug_msm_sharded_sim", "lemsm_debug_lhs_sharded_sim",
     "lemsm_prepare_scalar_witness_batch", "lemsm_table_entries",
+    "lemsm_divisor_witness", "lemsm_divisor_witness_device", "lemsm_divisor_last_ntt", "lemsm_lhs_witness", "lemsm_debug_ntt",
 ]
 
 
@@ -142,6 +144,11 @@ def load() -> ctypes.CDLL:
         "lemsm_debug_lhs_sharded_sim": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, i, u64p, u64p, szp]),
         "lemsm_prepare_scalar_witness_batch": (i, [vp, u8p, u8p, sz, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint32, u8p, szp]),
         "lemsm_table_entries": (i, [vp, i, ctypes.c_uint8, ctypes.c_uint64, sz, u64p]),
+        "lemsm_divisor_witness": (i, [vp, i, u64p, sz, i, i, u64p, sz, szp, u64p, sz, szp, u64p]),
+        "lemsm_divisor_witness_device": (i, [vp, i, vp, sz, i, i, u64p, sz, szp, u64p, sz, szp, u64p]),
+        "lemsm_divisor_last_ntt": (i, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
+        "lemsm_lhs_witness": (i, [vp, i, u8p, u64p, sz, ctypes.c_uint8, u64p, u64p, sz, szp, i, szp]),
+        "lemsm_debug_ntt": (i, [vp, u64p, u64p, sz, ctypes.c_uint32, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

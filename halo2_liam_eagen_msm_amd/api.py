@@ -74,6 +74,10 @@ class RefIndexOutOfBounds(LemsmError, IndexError):
         self.index = index
 
 
+class SumNotIdentity(LemsmError, AssertionError):
+    """reference: `if tmp.1 != C::identity() {panic!()}` (src/regular_functions_utils.rs:478)"""
+
+
 class RefArithmeticOverflow(LemsmError, OverflowError):
     """reference (debug build): `attempt to multiply / add with overflow` in pow or += at src/negbase_utils.rs:97-101"""
 
@@ -180,6 +184,8 @@ class Context:
             raise ScalarOutOfRange(rc, msg, bad_index)
         if rc == _lib.LEMSM_ERR_BAD_BASE:
             raise BadBase(rc, msg)
+        if rc == _lib.LEMSM_ERR_SUM_NOT_IDENTITY:
+            raise SumNotIdentity(rc, msg)
         if rc in (_lib.LEMSM_ERR_TOO_MANY_DIGITS, _lib.LEMSM_ERR_INDEX_OUT_OF_BOUNDS, _lib.LEMSM_ERR_ARITH_OVERFLOW):
             if bad_index is None:
                 bad_index = int(self.lib.lemsm_last_bad_index(self.h))
@@ -312,6 +318,59 @@ class Context:
         s = _scalars(scalars)
         out = np.zeros((s.shape[0], d), np.uint8)
         self._check(self.lib.lemsm_negbase_decompose_batch(self.h, _ptr(s), s.shape[0], base, d, _ptr(out)))
+        return out
+
+    # ---- divisor witness ------------------------------------------------------------------
+    def divisor_witness(self, curve, points_affine, require_zero_sum: bool = True, normalise: bool = True):
+        """compute_divisor_witness{,_partial} (src/regular_functions_utils.rs:453-480) on the GPU.
+        Returns (a, b, out_point): coefficient arrays (len, 4) of raw Montgomery limbs -- lengths exactly the reference's --
+        and the tree's output point (affine, zeros = identity)."""
+        p = _limbs(points_affine, 8)
+        n = p.shape[0]
+        cap = n + 4
+        a = np.zeros((cap, 4), np.uint64); b = np.zeros((cap, 4), np.uint64)
+        la = ctypes.c_size_t(); lb = ctypes.c_size_t()
+        outp = np.zeros(8, np.uint64)
+        self._check(self.lib.lemsm_divisor_witness(self.h, _curve_id(curve), _ptr(p) if n else None, n, int(require_zero_sum), int(normalise),
+                                                   _ptr(a), cap, ctypes.byref(la), _ptr(b), cap, ctypes.byref(lb), _ptr(outp)))
+        return a[: la.value].copy(), b[: lb.value].copy(), outp
+
+    def divisor_last_ntt(self) -> Tuple[float, int]:
+        ms = ctypes.c_double(); by = ctypes.c_uint64()
+        self._check(self.lib.lemsm_divisor_last_ntt(self.h, ctypes.byref(ms), ctypes.byref(by)))
+        return ms.value, by.value
+
+    def lhs_witness(self, curve, scalars, pts_jacobian, base: int, normalise: bool = True):
+        """compute_lhs_witness in full (src/argument_witness_calc.rs:87-136): (carry, [(a, b)] * d) with the functions in the
+        reference's (reversed) order."""
+        cid = _curve_id(curve)
+        s = _scalars(scalars)
+        p = _limbs(pts_jacobian, 12)
+        if s.shape[0] != p.shape[0]:
+            raise LengthMismatch(_lib.LEMSM_ERR_LEN_MISMATCH, "incompatible amount of coefficients")
+        if not (3 <= base <= 255):
+            raise BadBase(_lib.LEMSM_ERR_BAD_BASE, "base must be in 3..=255")
+        n = s.shape[0]
+        d = num_digits(cid, base)
+        cap = d * (n + base + 4)
+        coeffs = np.zeros((cap, 4), np.uint64)
+        index = np.zeros((d, 4), np.uintp)
+        carry = np.zeros(12, np.uint64)
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_lhs_witness(self.h, cid, _ptr(s) if n else None, _ptr(p) if n else None, n, base, _ptr(carry), _ptr(coeffs), cap, _ptr(index),
+                                        int(normalise), ctypes.byref(bad))
+        self._check(rc, bad.value)
+        fns = []
+        for f in range(d):
+            oa, la, ob, lb = (int(v) for v in index[f])
+            fns.append((coeffs[oa: oa + la].copy(), coeffs[ob: ob + lb].copy()))
+        return carry, fns
+
+    def debug_ntt(self, data, logn: int, inverse: bool = False) -> np.ndarray:
+        a = _limbs(data, 4)
+        assert a.shape[0] % (1 << logn) == 0
+        out = np.zeros_like(a)
+        self._check(self.lib.lemsm_debug_ntt(self.h, _ptr(a), _ptr(out), a.shape[0] >> logn, logn, int(inverse)))
         return out
 
     # ---- prepare_scalar_witness / table_entry_by_id ---------------------------------------
@@ -597,11 +656,26 @@ def best_multiexp(coeffs, bases, curve="bn254_g1", ctx: Optional[Context] = None
     return (ctx or default_context()).msm(curve, coeffs, bases)
 
 
-def compute_lhs_witness(scalars, pts, base: int, curve="grumpkin", ctx: Optional[Context] = None):
-    """Returns (carry, per_digit_carries): `.0` of the reference's return value and the carries
-    its `ret` vector is built from (each RegularFunction = compute_divisor_witness of a point list
-    ending in -carry_i; that polynomial step stays on the Rust side)."""
-    return (ctx or default_context()).lhs_msm(curve, scalars, pts, base, True)
+def compute_lhs_witness(scalars, pts, base: int, curve="grumpkin", ctx: Optional[Context] = None, normalise: bool = True):
+    """The reference's return value (C, Vec<RegularFunction<C>>) (src/argument_witness_calc.rs:87, :134): the carry
+    sum_j scalars[j] * pts[j] as a Jacobian point and the d divisor witnesses of :129 as (a, b) coefficient arrays
+    (raw Montgomery limbs), in the reference's reversed order (:132).  A RegularFunction is defined up to a scalar
+    (linefunc takes whatever projective representative a point has); normalise=True returns the representative whose
+    coefficient of highest pole order is 1."""
+    return (ctx or default_context()).lhs_witness(curve, scalars, pts, base, normalise)
+
+
+def compute_divisor_witness(pts_affine, curve="grumpkin", ctx: Optional[Context] = None, normalise: bool = True):
+    """src/regular_functions_utils.rs:476-480: (a, b) of the regular function vanishing on the points; raises
+    SumNotIdentity where the reference panics (:478)."""
+    a, b, _ = (ctx or default_context()).divisor_witness(curve, pts_affine, True, normalise)
+    return a, b
+
+
+def compute_divisor_witness_partial(pts_affine, curve="grumpkin", ctx: Optional[Context] = None, normalise: bool = True):
+    """src/regular_functions_utils.rs:453-467: ((a, b), output point as affine raw limbs, zeros = identity)"""
+    a, b, out = (ctx or default_context()).divisor_witness(curve, pts_affine, False, normalise)
+    return (a, b), out
 
 
 def _neg_affine_raw(curve_id: int, pts: np.ndarray) -> np.ndarray:

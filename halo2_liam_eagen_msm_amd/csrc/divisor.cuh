@@ -1,0 +1,418 @@
+// Divisor witness on the GPU: compute_divisor_witness / Propagation::group_merge of the reference
+// (/root/reference/src/regular_functions_utils.rs:222-273 RegularFunction, :285-303 linefunc, :311-405 Propagation,
+// :453-480 compute_divisor_witness{_partial}; the polynomial products of :54-62 / :102-129 / :209-216).
+//
+// Shape of the computation.  The reference pairs the points up (from_pair, :457-463) and merges neighbours level by
+// level (group_merge, :380-405): node k of level l+1 = merge(node 2k, node 2k+1 of level l), a lone last node passes
+// through.  That is a perfect binary tree over the index range with a ragged right edge, so every level is ONE batch:
+//   * the nodes' outputs (points) are added in XYZZ and brought to affine with one batched inversion per level;
+//   * merge (:333-360) is, per node, numerator = L.w * (R.w * line(-L.out, -R.out)) divided twice by (x - Lx), (x - Rx)
+//     (kate_div: exact synthetic division), or the plain product L.w * R.w when an output is the identity.
+//     Both are POINTWISE in an evaluation domain: with a(x) + y b(x) evaluated at x_i = omega^i,
+//       (a1 + y b1)(a2 + y b2) = a1 a2 + b1 b2 (x^3 + B) + y (a1 b2 + b1 a2)          (:266-273, y^2 = x^3 + B)
+//     and the division by (x - c) is a division of both parts by (x_i - c).  So one level = 4 forward NTTs per node
+//     (L.a, L.b, R.a, R.b), one pointwise kernel (with a batched inversion of the denominators), 2 inverse NTTs.
+//     The transform size N only has to hold the QUOTIENT (the numerator is never interpolated).  The domain is a COSET
+//     g omega^i (g = a power of 7, the field's multiplicative generator): x_i - c = 0 would need c to be g times a
+//     root of unity -- with g = 1 the Grumpkin generator itself (x = 1) would hit it; a zero denominator is detected
+//     and the level redone with the next power of 7.  Exact arithmetic:
+//     the coefficients are those of the reference's mul_naive / mul_fft / kate_div, whatever the algorithm.
+//   * polynomial LENGTHS follow the reference's bookkeeping exactly (trailing zeros it carries are carried here):
+//     len(p*q) = len p + len q - 1 (:55, :104), len(p+q) = max (:183), kate_div: len - 1; two empty operands are the
+//     reference's usize underflow at :55 (a panic) and are reported, not computed.
+//
+// A witness is defined up to a non-zero scalar: linefunc (:285-303) builds its line from PROJECTIVE coordinates of
+// whatever Jacobian representative a point has (:426-431); here lines are built from affine coordinates.  The C ABI
+// offers the normalised form (leading coefficient by pole order = 1), which is representation-independent.
+//
+// Field: bn256::Fr = the base field of Grumpkin, the only field the reference implements FftPrecomp for
+// (src/precomputed_fft_data.rs:3; compute_lhs_witness is bounded by it, src/argument_witness_calc.rs:87).  Strict
+// 8 x 32-bit Montgomery arithmetic (field32.cuh), 32-byte canonical storage = the C ABI's raw Montgomery limbs.
+#pragma once
+#include "xyzz.cuh"
+
+namespace lemsm {
+namespace dw {
+
+typedef Field32<FrParams> F;
+typedef XYZZ<F> G;
+typedef F::fe fe;
+
+enum { MODE_PASS = 0, MODE_PRODUCT = 1, MODE_DIVIDE = 2 };
+enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_WORDS = 4 };
+
+// what k_plan decides for one node of the next level
+struct Plan {
+  u32 mode, la, lb, pad;
+  u32 c0[8], c1[8], d0[8];   // line(-L.out, -R.out) = (c0 + c1 x) + y d0      (from_line(lx, ly, lz): a = [lz, lx], b = [ly], :244-246)
+  u32 lx[8], rx[8];          // affine x of L.out, R.out (the two kate_div points, :351-357)
+};
+
+__device__ __forceinline__ void ld(fe& r, const u32* p) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = p[i];
+}
+__device__ __forceinline__ void st(u32* p, const fe& a) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) p[i] = a.v[i];
+}
+__device__ __forceinline__ bool aff_id(const fe& x, const fe& y) { return F::is_zero(x) && F::is_zero(y); }
+
+// line through two affine, non-identity points P = (x1,y1), Q = (x2,y2): lx x + ly y + lz with
+// lx = y1 - y2, ly = x2 - x1, lz = x1 y2 - y1 x2  (linefunc :290-292 with z = 1); all zero iff P == Q.
+__device__ __forceinline__ bool line_through(fe& lx, fe& ly, fe& lz, const fe& x1, const fe& y1, const fe& x2, const fe& y2) {
+  fe t, u;
+  F::sub(lx, y1, y2); F::sub(ly, x2, x1);
+  F::mul(t, x1, y2); F::mul(u, y1, x2); F::sub(lz, t, u);
+  return !(F::is_zero(lx) && F::is_zero(ly) && F::is_zero(lz));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// points
+// ---------------------------------------------------------------------------------------------------------
+// leaves: sum[k] = -(pts[2k] + pts[2k+1]) (a lone last point: -pts[2k]) as XYZZ               (:321, :330)
+__global__ __launch_bounds__(256) void k_leaf_sum(const uint4* __restrict__ pts, u32 n, u32 nleaf, char* __restrict__ out_xyzz) {
+  u32 k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nleaf) return;
+  G::pt acc; G::set_identity(acc);
+  for (u32 t = 0; t < 2; t++) {
+    u32 j = 2 * k + t;
+    if (j >= n) break;
+    fe x, y; F::load(x, pts + (size_t)j * 4); F::load(y, pts + (size_t)j * 4 + 2);
+    if (!aff_id(x, y)) G::madd(acc, x, y);
+  }
+  F::neg(acc.y, acc.y);
+  G::store(out_xyzz + (size_t)k * 128, acc);
+}
+
+// inner nodes: sum[k] = child[2k] + child[2k+1] (affine children; a lone child passes through)   (:335)
+__global__ __launch_bounds__(256) void k_merge_sum(const uint4* __restrict__ child_aff, u32 nchild, u32 nnodes, char* __restrict__ out_xyzz) {
+  u32 k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nnodes) return;
+  G::pt acc; G::set_identity(acc);
+  for (u32 t = 0; t < 2; t++) {
+    u32 j = 2 * k + t;
+    if (j >= nchild) break;
+    fe x, y; F::load(x, child_aff + (size_t)j * 4); F::load(y, child_aff + (size_t)j * 4 + 2);
+    if (!aff_id(x, y)) G::madd(acc, x, y);
+  }
+  G::store(out_xyzz + (size_t)k * 128, acc);
+}
+
+// XYZZ -> affine, Montgomery's trick over KB points per thread (prefix products in scratch[k][thread]); identity -> (0,0)
+template <int KB>
+__global__ __launch_bounds__(256) void k_to_affine(const char* __restrict__ xyzz, u32 cnt, uint4* __restrict__ aff, char* __restrict__ scratch) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+  const u64 j0 = (u64)t * KB;
+  if (j0 >= cnt) return;
+  const u32 m = (u32)min((u64)KB, (u64)cnt - j0);
+  fe acc; F::set_one(acc);
+  for (u32 k = 0; k < m; k++) {
+    G::pt p; G::load(p, xyzz + (j0 + k) * 128);
+    F::store(scratch + ((size_t)k * nthreads + t) * 32, acc);
+    if (!G::is_identity(p)) F::mul(acc, acc, p.zzz);
+  }
+  fe inv; F::inv(inv, acc);
+  for (u32 k = m; k-- > 0;) {
+    G::pt p; G::load(p, xyzz + (j0 + k) * 128);
+    uint4* o = aff + (j0 + k) * 4;
+    if (G::is_identity(p)) { o[0] = make_uint4(0, 0, 0, 0); o[1] = o[0]; o[2] = o[0]; o[3] = o[0]; continue; }
+    fe pref, izzz, iz, izz, x, y;
+    F::load(pref, scratch + ((size_t)k * nthreads + t) * 32);
+    F::mul(izzz, inv, pref);
+    F::mul(inv, inv, p.zzz);
+    F::mul(iz, p.zz, izzz); F::sqr(izz, iz);        // ZZ/ZZZ = 1/Z ; (1/Z)^2 = 1/ZZ
+    F::mul(x, p.x, izz); F::mul(y, p.y, izzz);
+    F::store(o, x); F::store(o + 2, y);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// leaves: the line of every pair (from_pair :328-331, from_point :319-322, empty :324-326)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_leaf_lines(const uint4* __restrict__ pts, u32 n, u32 nleaf, const uint4* __restrict__ out_aff,
+                                                    u32* __restrict__ A, u32* __restrict__ B, u32 capA, u32 capB, uint2* __restrict__ lens) {
+  u32 k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nleaf) return;
+  fe x1, y1, x2, y2, zero, one;
+  F::set_zero(zero); F::set_one(one);
+  F::load(x1, pts + (size_t)(2 * k) * 4); F::load(y1, pts + (size_t)(2 * k) * 4 + 2);
+  const bool lone = 2 * k + 1 >= n;
+  if (lone) { x2 = zero; y2 = zero; } else { F::load(x2, pts + (size_t)(2 * k + 1) * 4); F::load(y2, pts + (size_t)(2 * k + 1) * 4 + 2); }
+  const bool id1 = aff_id(x1, y1), id2 = aff_id(x2, y2);
+  u32* a = A + (size_t)k * capA * 8; u32* b = B + (size_t)k * capB * 8;
+  fe lx, ly, lz;
+  if (id1 && id2) {                       // empty(): wtns = 1, no y part
+    st(a, one); lens[k] = make_uint2(1, 0);
+    return;
+  }
+  if (id1 || id2 || lone) {
+    // one real point q.  from_point(q) = linefunc(q, -q) (:321): lx = 2 qy, ly = 0, lz = -2 qx qy;
+    // from_pair(q, O) = linefunc(q, O) (:330): the vertical line through q as well (lx = -1, ly = 0, lz = qx with O = (0,1,0)).
+    // Either way a scalar multiple of (x - qx); the first form is used for both.
+    const fe& qx = id1 ? x2 : x1; const fe& qy = id1 ? y2 : y1;
+    fe t;
+    F::dbl(lx, qy); F::mul(t, qx, lx); F::neg(lz, t); ly = zero;
+  } else if (!line_through(lx, ly, lz, x1, y1, x2, y2)) {
+    // p1 == p2: the tangent, as the line through p1 and c = -(p1 + p2) = this leaf's output (:298-302)
+    fe cx, cy; F::load(cx, out_aff + (size_t)k * 4); F::load(cy, out_aff + (size_t)k * 4 + 2);
+    line_through(lx, ly, lz, x1, y1, cx, cy);
+  }
+  st(a, lz); st(a + 8, lx); st(b, ly);    // from_line(lx, ly, lz): a = [lz, lx], b = [ly]
+  lens[k] = make_uint2(2, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// plan of one level: mode, line, lengths (the reference's length bookkeeping, see the header comment)
+// ---------------------------------------------------------------------------------------------------------
+// len(p * q) per mul_naive :55 / mul_fft :104; both empty = usize underflow (panic)
+__device__ __forceinline__ u32 plen(u32 a, u32 b, bool& panic) {
+  if (a + b == 0) { panic = true; return 0; }
+  return a + b - 1;
+}
+// lengths of (a1 + y b1)(a2 + y b2)  (:266-273: subst_y2 has 4 coefficients)
+__device__ __forceinline__ void rf_len(u32& la, u32& lb, u32 a1, u32 b1, u32 a2, u32 b2, bool& panic) {
+  u32 aa = plen(a1, a2, panic), bb = plen(b1, b2, panic);
+  u32 bbs = plen(bb, 4, panic);
+  u32 ab = plen(a1, b2, panic), ba = plen(b1, a2, panic);
+  la = max(aa, bbs); lb = max(ab, ba);
+}
+
+__global__ __launch_bounds__(256) void k_plan(const uint4* __restrict__ child_aff, const uint2* __restrict__ child_lens, u32 nchild, u32 nnodes,
+                                              const uint4* __restrict__ node_aff, Plan* __restrict__ plan, u32* __restrict__ stats) {
+  u32 k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nnodes) return;
+  Plan pl; pl.pad = 0;
+  const u32 L = 2 * k, R = 2 * k + 1;
+  uint2 ll = child_lens[L];
+  if (R >= nchild) {                                  // MaybePair::Unit: passes through unchanged (:363-366)
+    pl.mode = MODE_PASS; pl.la = ll.x; pl.lb = ll.y;
+    plan[k] = pl;
+    atomicMax(&stats[STAT_MAXLEN], max(ll.x, ll.y));
+    return;
+  }
+  uint2 rl = child_lens[R];
+  fe lx_, ly_, rx_, ry_;
+  F::load(lx_, child_aff + (size_t)L * 4); F::load(ly_, child_aff + (size_t)L * 4 + 2);
+  F::load(rx_, child_aff + (size_t)R * 4); F::load(ry_, child_aff + (size_t)R * 4 + 2);
+  bool panic = false;
+  if (aff_id(lx_, ly_) || aff_id(rx_, ry_)) {         // :340-342
+    pl.mode = MODE_PRODUCT;
+    rf_len(pl.la, pl.lb, ll.x, ll.y, rl.x, rl.y, panic);
+  } else {
+    pl.mode = MODE_DIVIDE;
+    // line through -L.out and -R.out (:344); equal points: through -L.out and c = -((-L.out) + (-R.out)) = this node's output
+    fe nly, nry, lx, ly, lz;
+    F::neg(nly, ly_); F::neg(nry, ry_);
+    if (!line_through(lx, ly, lz, lx_, nly, rx_, nry)) {
+      fe cx, cy; F::load(cx, node_aff + (size_t)k * 4); F::load(cy, node_aff + (size_t)k * 4 + 2);
+      line_through(lx, ly, lz, lx_, nly, cx, cy);
+    }
+    st(pl.c0, lz); st(pl.c1, lx); st(pl.d0, ly); st(pl.lx, lx_); st(pl.rx, rx_);
+    u32 ta, tb, na, nb;
+    rf_len(ta, tb, rl.x, rl.y, 2, 1, panic);          // b.wtns * linefunc
+    rf_len(na, nb, ll.x, ll.y, ta, tb, panic);        // a.wtns * (..)
+    if (na < 2 || nb < 2) panic = true;               // kate_division of an empty vector (len - 1 underflows)
+    pl.la = na - 2; pl.lb = nb - 2;                    // two kate_div each (:357)
+  }
+  plan[k] = pl;
+  if (panic) atomicOr(&stats[STAT_PANIC], 1u);
+  else atomicMax(&stats[STAT_MAXLEN], max(pl.la, pl.lb));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NTT over Fr, batched: nseq sequences of N = 2^logN contiguous elements (32 B each).
+// W[t] = omega_Nmax^t for t < Nmax/2 (Montgomery form); ws = Nmax / N.
+// forward: decimation in frequency, natural order in -> bit-reversed order out;
+// inverse: decimation in time with omega^-1, bit-reversed in -> natural out (not scaled by 1/N: the pointwise kernel does).
+// One launch per stage, one butterfly per thread (HBM-bound: 128 B moved per butterfly and stage).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void twiddle(fe& w, const u32* __restrict__ W, u32 half_max, u32 t, bool inverse) {
+  // omega^t (t < Nmax/2) or omega^-t = -omega^(Nmax/2 - t)
+  if (!inverse || t == 0) { ld(w, W + (size_t)t * 8); return; }
+  fe p; ld(p, W + (size_t)(half_max - t) * 8); F::neg(w, p);
+}
+
+__global__ __launch_bounds__(256) void k_ntt_stage(u32* __restrict__ buf, u32 nseq, u32 logN, u32 logm /* span m = 2^logm */,
+                                                   const u32* __restrict__ W, u32 log_half_max, u32 inverse) {
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u32 half = 1u << (logN - 1);
+  if (gid >= (u64)nseq * half) return;
+  const u32 s = (u32)(gid >> (logN - 1)), bfly = (u32)gid & (half - 1);
+  const u32 m = 1u << logm, r = bfly & (m - 1);
+  const u32 i = ((bfly >> logm) << (logm + 1)) + r, j = i + m;
+  u32* base = buf + ((size_t)s << logN) * 8;
+  // omega_N^(r * N/(2m)) = omega_Nmax^(r * (N/2m) * (Nmax/N)) = W[r << (log_half_max - logm)]
+  const u32 t = r << (log_half_max - logm);
+  fe w; twiddle(w, W, 1u << log_half_max, t, inverse != 0);
+  fe u, v; ld(u, base + (size_t)i * 8); ld(v, base + (size_t)j * 8);
+  fe x, y;
+  if (!inverse) { F::add(x, u, v); F::sub(y, u, v); F::mul(y, y, w); }
+  else { F::mul(v, v, w); F::add(x, u, v); F::sub(y, u, v); }
+  st(base + (size_t)i * 8, x); st(base + (size_t)j * 8, y);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one level: load (zero-padded children into the transform buffer), pointwise, store
+// buffer layout: seq (q * nnodes + k), q = 0: L.a, 1: L.b, 2: R.a, 3: R.b; results overwrite q = 0 (a) and 1 (b)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_load(const u32* __restrict__ cA, const u32* __restrict__ cB, const uint2* __restrict__ child_lens,
+                                              u32 ccapA, u32 ccapB, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
+                                              const u32* __restrict__ GP /* g^i */, u32* __restrict__ buf) {
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 per = (u64)nnodes << logN;
+  if (gid >= 4 * per) return;
+  const u32 q = (u32)(gid / per); const u64 rem = gid - (u64)q * per;
+  const u32 k = (u32)(rem >> logN), i = (u32)rem & ((1u << logN) - 1);
+  fe v; F::set_zero(v);
+  if (plan[k].mode != MODE_PASS) {
+    const u32 c = 2 * k + (q >> 1);
+    const uint2 cl = child_lens[c];
+    bool have = false;
+    if (q & 1) { if (i < cl.y) { ld(v, cB + ((size_t)c * ccapB + i) * 8); have = true; } }
+    else { if (i < cl.x) { ld(v, cA + ((size_t)c * ccapA + i) * 8); have = true; } }
+    if (have && i) { fe g; ld(g, GP + (size_t)i * 8); F::mul(v, v, g); }   // p(g x): coefficient i times g^i (coset evaluation)
+  }
+  st(buf + gid * 8, v);
+}
+
+// x_i of the (bit-reversed) slot i of a size-N transform: omega_N^rev(i)
+__device__ __forceinline__ void eval_point(fe& x, const u32* __restrict__ W, u32 log_half_max, u32 logN, u32 i) {
+  const u32 j = __brev(i) >> (32 - logN);
+  const u32 halfN = 1u << (logN - 1);
+  if (j < halfN) ld(x, W + ((size_t)j << (log_half_max + 1 - logN)) * 8);
+  else { fe p; ld(p, W + ((size_t)(j - halfN) << (log_half_max + 1 - logN)) * 8); F::neg(x, p); }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
+                                                   const u32* __restrict__ W, u32 log_half_max, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
+                                                   u32* __restrict__ stats) {
+  const u32 N = 1u << logN;
+  const u32 chunks = (N + KB - 1) / KB;
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (u64)nnodes * chunks) return;
+  const u32 k = (u32)(gid / chunks), ch = (u32)(gid - (u64)k * chunks);
+  const Plan& pl = plan[k];
+  if (pl.mode == MODE_PASS) return;
+  const u32 i0 = ch * KB, i1 = min(N, i0 + KB);
+  const size_t per = (size_t)nnodes << logN;
+  u32* sLa = buf + (((size_t)k << logN)) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
+  fe cb, ninv, cg; ld(cb, consts); ld(ninv, consts + 8); ld(cg, consts + 16);
+  fe c0, c1, d0, lxx, rxx;
+  const bool divide = pl.mode == MODE_DIVIDE;
+  if (divide) { ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0); ld(lxx, pl.lx); ld(rxx, pl.rx); }
+  // pass 1: numerators into the L.a / L.b slots, running product of the denominators into the R.a slot
+  fe run; F::set_one(run);
+  for (u32 i = i0; i < i1; i++) {
+    fe x, x3, s, La, Lb, Ra, Rb, A, Bv, t, u;
+    eval_point(x, W, log_half_max, logN, i); F::mul(x, x, cg);          // x_i = g omega^rev(i): the coset keeps x_i - c != 0
+    F::sqr(t, x); F::mul(x3, t, x); F::add(s, x3, cb);                 // s = x^3 + B  (y^2)
+    ld(La, sLa + (size_t)i * 8); ld(Lb, sLb + (size_t)i * 8); ld(Ra, sRa + (size_t)i * 8); ld(Rb, sRb + (size_t)i * 8);
+    if (divide) {
+      fe l, tA, tB;
+      F::mul(l, c1, x); F::add(l, l, c0);                               // c0 + c1 x
+      F::mul(tA, Ra, l); F::mul(t, Rb, d0); F::mul(t, t, s); F::add(tA, tA, t);     // R.a l + R.b d0 s
+      F::mul(tB, Ra, d0); F::mul(t, Rb, l); F::add(tB, tB, t);                        // R.a d0 + R.b l
+      F::mul(A, La, tA); F::mul(t, Lb, tB); F::mul(t, t, s); F::add(A, A, t);
+      F::mul(Bv, La, tB); F::mul(t, Lb, tA); F::add(Bv, Bv, t);
+      fe den; F::sub(t, x, lxx); F::sub(u, x, rxx); F::mul(den, t, u);
+      if (F::is_zero(den)) { atomicOr(&stats[STAT_ZERODEN], 1u); F::set_one(den); }
+      st(sRa + (size_t)i * 8, run);                                      // prefix product before this element
+      st(sRb + (size_t)i * 8, den);
+      F::mul(run, run, den);
+    } else {
+      F::mul(A, La, Ra); F::mul(t, Lb, Rb); F::mul(t, t, s); F::add(A, A, t);
+      F::mul(Bv, La, Rb); F::mul(t, Lb, Ra); F::add(Bv, Bv, t);
+    }
+    F::mul(A, A, ninv); F::mul(Bv, Bv, ninv);                            // 1/N of the inverse transform
+    st(sLa + (size_t)i * 8, A); st(sLb + (size_t)i * 8, Bv);
+  }
+  if (!divide) return;
+  // pass 2: Montgomery's trick backwards
+  fe inv; F::inv(inv, run);
+  for (u32 i = i1; i-- > i0;) {
+    fe pref, den, di, A, Bv;
+    ld(pref, sRa + (size_t)i * 8); ld(den, sRb + (size_t)i * 8);
+    F::mul(di, inv, pref); F::mul(inv, inv, den);
+    ld(A, sLa + (size_t)i * 8); ld(Bv, sLb + (size_t)i * 8);
+    F::mul(A, A, di); F::mul(Bv, Bv, di);
+    st(sLa + (size_t)i * 8, A); st(sLb + (size_t)i * 8, Bv);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_store(const u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
+                                               const u32* __restrict__ cA, const u32* __restrict__ cB, u32 ccapA, u32 ccapB,
+                                               u32* __restrict__ nA, u32* __restrict__ nB, u32 capA, u32 capB, uint2* __restrict__ lens,
+                                               const u32* __restrict__ GI /* g^-i */) {
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u32 cap = max(capA, capB);
+  if (gid >= (u64)nnodes * cap) return;
+  const u32 k = (u32)(gid / cap), i = (u32)(gid - (u64)k * cap);
+  const Plan& pl = plan[k];
+  if (i == 0) lens[k] = make_uint2(pl.la, pl.lb);
+  const size_t per = (size_t)nnodes << logN;
+  fe v;
+  if (i < pl.la) {
+    if (pl.mode == MODE_PASS) ld(v, cA + ((size_t)(2 * k) * ccapA + i) * 8);
+    else { ld(v, buf + (((size_t)k << logN) + i) * 8); if (i) { fe g; ld(g, GI + (size_t)i * 8); F::mul(v, v, g); } }
+    st(nA + ((size_t)k * capA + i) * 8, v);
+  }
+  if (i < pl.lb) {
+    if (pl.mode == MODE_PASS) ld(v, cB + ((size_t)(2 * k) * ccapB + i) * 8);
+    else { ld(v, buf + (per + ((size_t)k << logN) + i) * 8); if (i) { fe g; ld(g, GI + (size_t)i * 8); F::mul(v, v, g); } }
+    st(nB + ((size_t)k * capB + i) * 8, v);
+  }
+}
+
+// W[t] = omega^t, t < count: omega^t = prod over the set bits b of t of P2[b] = omega^(2^b)
+__global__ __launch_bounds__(256) void k_twiddles(const u32* __restrict__ P2, u32 nbits, u32 count, u32* __restrict__ W) {
+  u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= count) return;
+  fe acc; F::set_one(acc);
+  for (u32 b = 0; b < nbits; b++)
+    if ((t >> b) & 1u) { fe p; ld(p, P2 + (size_t)b * 8); F::mul(acc, acc, p); }
+  st(W + (size_t)t * 8, acc);
+}
+
+// normalise: every coefficient times `scale` (the inverse of the leading coefficient by pole order)
+__global__ __launch_bounds__(256) void k_scale(u32* __restrict__ p, u32 cnt, const u32* __restrict__ scale) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  fe s, v; ld(s, scale); ld(v, p + (size_t)i * 8); F::mul(v, v, s); st(p + (size_t)i * 8, v);
+}
+
+// debug / KAT: plain forward or inverse transform of nseq sequences in natural order (bit reversal applied on the way in/out)
+__global__ __launch_bounds__(256) void k_bitrev_copy(const u32* __restrict__ in, u32* __restrict__ out, u32 nseq, u32 logN) {
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= ((u64)nseq << logN)) return;
+  const u32 s = (u32)(gid >> logN), i = (u32)gid & ((1u << logN) - 1);
+  const u32 j = logN ? (__brev(i) >> (32 - logN)) : 0;
+  fe v; ld(v, in + gid * 8); st(out + (((size_t)s << logN) + j) * 8, v);
+}
+
+// tmp lists of compute_lhs_witness (src/argument_witness_calc.rs:110-127): flags and gather
+__global__ __launch_bounds__(256) void k_lhs_flags(const uint8_t* __restrict__ digitsT /* d x n position-major, LSB-first positions */, u32 n, u32 pos, u32* __restrict__ flags) {
+  u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  flags[j] = digitsT[(size_t)pos * n + j] ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_lhs_gather(const uint8_t* __restrict__ digitsT, u32 n, u32 pos, u32 base, const u32* __restrict__ offs,
+                                                    const uint4* __restrict__ table /* n x (base-1) affine */, u32 lead, uint4* __restrict__ out) {
+  u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  u32 dg = digitsT[(size_t)pos * n + j];
+  if (!dg) return;
+  const uint4* s = table + ((size_t)j * (base - 1) + (dg - 1)) * 4;      // precomputed_points[j][id_by_digit(digit)]  :123
+  uint4* o = out + ((size_t)lead + offs[j]) * 4;
+  o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+}
+// out[i] = pt for i < count (the `base` copies of -carry, :112-116) ; and single-slot writes
+__global__ __launch_bounds__(256) void k_fill_points(const uint4* __restrict__ pt, u32 count, uint4* __restrict__ out) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  out[(size_t)i * 4] = pt[0]; out[(size_t)i * 4 + 1] = pt[1]; out[(size_t)i * 4 + 2] = pt[2]; out[(size_t)i * 4 + 3] = pt[3];
+}
+
+}  // namespace dw
+}  // namespace lemsm

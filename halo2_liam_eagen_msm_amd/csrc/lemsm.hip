@@ -16,6 +16,8 @@
 #include "hostmath.hpp"
 #include "kernels.cuh"
 #include "rccl_dyn.hpp"
+#include "divisor.cuh"
+#include <rocprim/rocprim.hpp>
 #include <functional>
 #include <thread>
 
@@ -91,6 +93,9 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   DevBuf gather;    // multi-GPU: all ranks' raw per-window records after the all-gather
+  DevBuf dw_tab, dw_arena, dw_tmp;   // divisor witness: twiddle / coset tables, level workspace, tmp point list
+  u32 dw_logn = 0, dw_gexp = 0;      // tables hold transforms up to 2^dw_logn with coset generator 7^dw_gexp
+  double dw_ntt_ms = 0; u64 dw_ntt_bytes = 0;
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;
@@ -1262,6 +1267,7 @@ const char* lemsm_strerror(int s) {
     case LEMSM_ERR_RCCL: return "RCCL error";
     case LEMSM_ERR_INDEX_OUT_OF_BOUNDS: return "index out of bounds";
     case LEMSM_ERR_ARITH_OVERFLOW: return "arithmetic overflow";
+    case LEMSM_ERR_SUM_NOT_IDENTITY: return "points do not sum to the identity";
     default: return "unknown status";
   }
 }
@@ -1297,7 +1303,7 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   if (ctx->stream_tail) { (void)hipStreamSynchronize(ctx->stream_tail); (void)hipStreamDestroy(ctx->stream_tail); }
   for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
   if (ctx->comm) { (void)Rccl::get().CommDestroy(ctx->comm); ctx->comm = nullptr; }
-  for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather, &ctx->dw_tab, &ctx->dw_arena, &ctx->dw_tmp}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -2028,3 +2034,5 @@ int lemsm_debug_pointop(lemsm_ctx* ctx, int curve, int op, const uint64_t* acc, 
 }
 
 }  // extern "C"
+
+#include "divisor_abi.inc"

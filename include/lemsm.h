@@ -65,7 +65,8 @@ enum lemsm_status {
   LEMSM_ERR_TOO_MANY_DIGITS = 8,
   LEMSM_ERR_RCCL = 9,
   LEMSM_ERR_INDEX_OUT_OF_BOUNDS = 10,
-  LEMSM_ERR_ARITH_OVERFLOW = 11
+  LEMSM_ERR_ARITH_OVERFLOW = 11,
+  LEMSM_ERR_SUM_NOT_IDENTITY = 12
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -225,6 +226,38 @@ int lemsm_lhs_partial_device(lemsm_ctx* ctx, int curve, const void* d_scalars, c
 int lemsm_lhs_combine(int curve, uint8_t base, const uint8_t* partials_all_positions,
                       uint64_t out_carry[12], uint64_t* out_carries);
 
+/* ---- divisor witness (the second return value of compute_lhs_witness) ----------------- */
+/* compute_divisor_witness_partial / compute_divisor_witness (src/regular_functions_utils.rs:453-480): the regular function
+   a(x) + y b(x) vanishing on the n points and on minus their sum, built by the reference's pairwise merge tree
+   (Propagation::group_merge :380-405) -- every level one GPU batch: NTTs over bn256::Fr, pointwise products with
+   y^2 = x^3 - 17 substituted (:266-273), the two exact divisions of merge (:357) done in the evaluation domain.
+   Grumpkin only (C::Base: FftPrecomp, src/precomputed_fft_data.rs:3).  points: n affine points, identity = (0,0).
+   out_a / out_b: coefficients, 4 raw-Montgomery limbs each, constant term first; *len_a / *len_b: the reference's vector
+   lengths exactly (trailing zero coefficients it carries included); n + 2 coefficients per part always suffice.
+   normalise != 0: scaled so that the coefficient of highest pole order (x^i: 2i, y x^i: 2i + 3) is 1.  A witness is only
+   defined up to a scalar (linefunc works on whatever projective representative a point has, :285-303, :426-431): the
+   normalised form is the representation-independent one.
+   require_zero_sum != 0: LEMSM_ERR_SUM_NOT_IDENTITY when the points do not sum to the identity (panic at :478).
+   out_point_affine (optional): the tree's output = minus the sum of the points (the `.1` of _partial).
+   LEMSM_ERR_ARITH_OVERFLOW: two empty polynomials meet in a product (usize underflow at :55, a panic in the reference:
+   four identity points in an aligned group of four). */
+int lemsm_divisor_witness(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, size_t n, int require_zero_sum,
+                          int normalise, uint64_t* out_a, size_t cap_a, size_t* len_a, uint64_t* out_b, size_t cap_b,
+                          size_t* len_b, uint64_t out_point_affine[8]);
+int lemsm_divisor_witness_device(lemsm_ctx* ctx, int curve, const void* d_points_affine, size_t n, int require_zero_sum,
+                                 int normalise, uint64_t* out_a, size_t cap_a, size_t* len_a, uint64_t* out_b,
+                                 size_t cap_b, size_t* len_b, uint64_t out_point_affine[8]);
+/* Device time (ms) and algorithmic bytes (2 x 32 B read + 2 x 32 B written per butterfly and stage) of the transform
+   stages of the last divisor-witness call: the figures its HBM roofline is priced with. */
+int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithmic_bytes);
+/* compute_lhs_witness in full (src/argument_witness_calc.rs:87-136): carry = sum_j scalars[j] pts[j] AND the d divisor
+   witnesses of :129 (function f = digit iteration d - 1 - f, the reference's `ret.reverse()` order).
+   out_coeffs: cap_coeffs field elements (4 limbs each); out_index: d x 4 entries {offset_a, len_a, offset_b, len_b} in
+   elements; d * (n + base + 4) elements always suffice. */
+int lemsm_lhs_witness(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* pts_jacobian, size_t n,
+                      uint8_t base, uint64_t out_carry[12], uint64_t* out_coeffs, size_t cap_coeffs, size_t* out_index,
+                      int normalise, size_t* bad_index);
+
 /* ---- precompute_multiplicities ------------------------------------------------------- */
 /* out[(k-1)] = k * pt for k = 1..base-1 (Jacobian), for each of n points:
    out_jacobian[(j*(base-1) + (k-1))*12 .. +12]. */
@@ -260,6 +293,9 @@ int lemsm_debug_montmul(lemsm_ctx* ctx, int curve, const uint64_t* a, const uint
 int lemsm_debug_fieldop(lemsm_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int lemsm_debug_pointop(lemsm_ctx* ctx, int curve, int op, const uint64_t* acc_xyzz, const uint64_t* q,
                         uint64_t* out_xyzz, size_t n);
+/* Plain transform over bn256::Fr of nseq sequences of 2^logn elements, natural order in and out, with the reference's
+   omega = FftPrecomp::omega_pow(S - logn) (src/regular_functions_utils.rs:111-124); the inverse is scaled by 1/N. */
+int lemsm_debug_ntt(lemsm_ctx* ctx, const uint64_t* in, uint64_t* out, size_t nseq, uint32_t logn, int inverse);
 /* One-GPU rehearsal of the sharded entries: the pipelines of all `world` ranks run one after the other on this
    context and their record areas are placed where the all-gather would put them; everything but the ncclAllGather
    call itself is the code of lemsm_*_sharded_device. */
