@@ -357,8 +357,8 @@ class Context:
         index = np.zeros((d, 4), np.uintp)
         carry = np.zeros(12, np.uint64)
         bad = ctypes.c_size_t(0)
-        rc = self.lib.lemsm_lhs_witness(self.h, cid, _ptr(s) if n else None, _ptr(p) if n else None, n, base, _ptr(carry), _ptr(coeffs), cap, _ptr(index),
-                                        int(normalise), ctypes.byref(bad))
+        rc = self.lib.lemsm_lhs_witness(self.h, cid, _ptr(s) if n else None, _ptr(p) if n else None, n, base, _ptr(carry), _ptr(coeffs), cap,
+                                        index.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), int(normalise), ctypes.byref(bad))
         self._check(rc, bad.value)
         fns = []
         for f in range(d):
