@@ -30,6 +30,7 @@
 // 8 x 32-bit Montgomery arithmetic (field32.cuh), 32-byte canonical storage = the C ABI's raw Montgomery limbs.
 #pragma once
 #include "xyzz.cuh"
+#include "field29.cuh"
 
 namespace lemsm {
 namespace dw {
@@ -45,7 +46,8 @@ enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_WORDS = 4 };
 struct Plan {
   u32 mode, la, lb, pad;
   u32 c0[8], c1[8], d0[8];   // line(-L.out, -R.out) = (c0 + c1 x) + y d0      (from_line(lx, ly, lz): a = [lz, lx], b = [ly], :244-246)
-  u32 lx[8], rx[8];          // affine x of L.out, R.out (the two kate_div points, :351-357)
+  u32 lX[8], lZZ[8], rX[8], rZZ[8];   // L.out, R.out as X / ZZ: the two kate_div points (:351-357) divide by (x - X/ZZ); here by
+                                      // (ZZ x - X), a scalar multiple -- the witness is only defined up to a scalar anyway
 };
 
 __device__ __forceinline__ void ld(fe& r, const u32* p) {
@@ -58,6 +60,30 @@ __device__ __forceinline__ void st(u32* p, const fe& a) {
 }
 __device__ __forceinline__ bool aff_id(const fe& x, const fe& y) { return F::is_zero(x) && F::is_zero(y); }
 
+// a^-1 (Montgomery form in, Montgomery form out) by Fermat in the lazy 29-bit field: 254 squarings of ~190 instructions
+// and ~130 products of ~225 instead of 381 products of ~370 (field32's inv) -- one inversion's latency is the floor of
+// every level's pointwise kernel.
+__device__ __noinline__ void inv_fast(fe& r, const fe& a) {
+  typedef Field29<Fr29Params> F29;
+  F29::fe x, acc;
+  F29::unpack(x, a.v); F29::from_abi(x, x);            // a 2^256 -> a 2^261 (the lazy field's domain)
+  F29::set_one(acc);
+  u32 e[8]; u32 bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) e[i] = __builtin_subc(FrParams::N[i], i == 0 ? 2u : 0u, bw, &bw);   // r - 2
+  for (int w = 0; w < 8; w++) {
+    u32 bits = e[w];
+    for (int j = 0; j < 32; j++) {
+      if (bits & 1u) F29::mul(acc, acc, x);
+      F29::sqr(x, x);
+      bits >>= 1;
+    }
+  }
+  F29::div32(acc, acc);                                  // back to the 2^256 domain
+  F29::canon(acc);
+  F29::pack(r.v, acc);
+}
+
 // line through two affine, non-identity points P = (x1,y1), Q = (x2,y2): lx x + ly y + lz with
 // lx = y1 - y2, ly = x2 - x1, lz = x1 y2 - y1 x2  (linefunc :290-292 with z = 1); all zero iff P == Q.
 __device__ __forceinline__ bool line_through(fe& lx, fe& ly, fe& lz, const fe& x1, const fe& y1, const fe& x2, const fe& y2) {
@@ -67,8 +93,21 @@ __device__ __forceinline__ bool line_through(fe& lx, fe& ly, fe& lz, const fe& x
   return !(F::is_zero(lx) && F::is_zero(ly) && F::is_zero(lz));
 }
 
+// the same through two points in homogeneous coordinates (X : Y : Z) -- linefunc :290-292 literally
+struct Hom { fe x, y, z; };
+__device__ __forceinline__ void hom_of(Hom& h, const G::pt& p) {          // x = X/ZZ, y = Y/ZZZ  ->  (X ZZZ : Y ZZ : ZZ ZZZ)
+  F::mul(h.x, p.x, p.zzz); F::mul(h.y, p.y, p.zz); F::mul(h.z, p.zz, p.zzz);
+}
+__device__ __forceinline__ bool line_through_hom(fe& lx, fe& ly, fe& lz, const Hom& a, const Hom& b) {
+  fe t, u;
+  F::mul(t, a.x, b.y); F::mul(u, a.y, b.x); F::sub(lz, t, u);
+  F::mul(t, a.y, b.z); F::mul(u, a.z, b.y); F::sub(lx, t, u);
+  F::mul(t, a.z, b.x); F::mul(u, a.x, b.z); F::sub(ly, t, u);
+  return !(F::is_zero(lx) && F::is_zero(ly) && F::is_zero(lz));
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// points
+// points: node outputs stay in XYZZ from level to level (no inversion anywhere in the tree)
 // ---------------------------------------------------------------------------------------------------------
 // leaves: sum[k] = -(pts[2k] + pts[2k+1]) (a lone last point: -pts[2k]) as XYZZ               (:321, :330)
 __global__ __launch_bounds__(256) void k_leaf_sum(const uint4* __restrict__ pts, u32 n, u32 nleaf, char* __restrict__ out_xyzz) {
@@ -85,17 +124,12 @@ __global__ __launch_bounds__(256) void k_leaf_sum(const uint4* __restrict__ pts,
   G::store(out_xyzz + (size_t)k * 128, acc);
 }
 
-// inner nodes: sum[k] = child[2k] + child[2k+1] (affine children; a lone child passes through)   (:335)
-__global__ __launch_bounds__(256) void k_merge_sum(const uint4* __restrict__ child_aff, u32 nchild, u32 nnodes, char* __restrict__ out_xyzz) {
+// inner nodes: out[k] = child[2k] + child[2k+1] (a lone child passes through)   (:335)
+__global__ __launch_bounds__(256) void k_merge_sum(const char* __restrict__ child_xyzz, u32 nchild, u32 nnodes, char* __restrict__ out_xyzz) {
   u32 k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nnodes) return;
-  G::pt acc; G::set_identity(acc);
-  for (u32 t = 0; t < 2; t++) {
-    u32 j = 2 * k + t;
-    if (j >= nchild) break;
-    fe x, y; F::load(x, child_aff + (size_t)j * 4); F::load(y, child_aff + (size_t)j * 4 + 2);
-    if (!aff_id(x, y)) G::madd(acc, x, y);
-  }
+  G::pt acc; G::load(acc, child_xyzz + (size_t)(2 * k) * 128);
+  if (2 * k + 1 < nchild) { G::pt q; G::load(q, child_xyzz + (size_t)(2 * k + 1) * 128); G::add(acc, q); }
   G::store(out_xyzz + (size_t)k * 128, acc);
 }
 
@@ -130,7 +164,7 @@ __global__ __launch_bounds__(256) void k_to_affine(const char* __restrict__ xyzz
 // ---------------------------------------------------------------------------------------------------------
 // leaves: the line of every pair (from_pair :328-331, from_point :319-322, empty :324-326)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_leaf_lines(const uint4* __restrict__ pts, u32 n, u32 nleaf, const uint4* __restrict__ out_aff,
+__global__ __launch_bounds__(256) void k_leaf_lines(const uint4* __restrict__ pts, u32 n, u32 nleaf, const char* __restrict__ out_xyzz,
                                                     u32* __restrict__ A, u32* __restrict__ B, u32 capA, u32 capB, uint2* __restrict__ lens) {
   u32 k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nleaf) return;
@@ -155,8 +189,9 @@ __global__ __launch_bounds__(256) void k_leaf_lines(const uint4* __restrict__ pt
     F::dbl(lx, qy); F::mul(t, qx, lx); F::neg(lz, t); ly = zero;
   } else if (!line_through(lx, ly, lz, x1, y1, x2, y2)) {
     // p1 == p2: the tangent, as the line through p1 and c = -(p1 + p2) = this leaf's output (:298-302)
-    fe cx, cy; F::load(cx, out_aff + (size_t)k * 4); F::load(cy, out_aff + (size_t)k * 4 + 2);
-    line_through(lx, ly, lz, x1, y1, cx, cy);
+    G::pt c; G::load(c, out_xyzz + (size_t)k * 128);
+    Hom ha, hc; ha.x = x1; ha.y = y1; F::set_one(ha.z); hom_of(hc, c);
+    line_through_hom(lx, ly, lz, ha, hc);
   }
   st(a, lz); st(a + 8, lx); st(b, ly);    // from_line(lx, ly, lz): a = [lz, lx], b = [ly]
   lens[k] = make_uint2(2, 1);
@@ -178,8 +213,8 @@ __device__ __forceinline__ void rf_len(u32& la, u32& lb, u32 a1, u32 b1, u32 a2,
   la = max(aa, bbs); lb = max(ab, ba);
 }
 
-__global__ __launch_bounds__(256) void k_plan(const uint4* __restrict__ child_aff, const uint2* __restrict__ child_lens, u32 nchild, u32 nnodes,
-                                              const uint4* __restrict__ node_aff, Plan* __restrict__ plan, u32* __restrict__ stats) {
+__global__ __launch_bounds__(256) void k_plan(const char* __restrict__ child_xyzz, const uint2* __restrict__ child_lens, u32 nchild, u32 nnodes,
+                                              const char* __restrict__ node_xyzz, Plan* __restrict__ plan, u32* __restrict__ stats) {
   u32 k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nnodes) return;
   Plan pl; pl.pad = 0;
@@ -192,23 +227,26 @@ __global__ __launch_bounds__(256) void k_plan(const uint4* __restrict__ child_af
     return;
   }
   uint2 rl = child_lens[R];
-  fe lx_, ly_, rx_, ry_;
-  F::load(lx_, child_aff + (size_t)L * 4); F::load(ly_, child_aff + (size_t)L * 4 + 2);
-  F::load(rx_, child_aff + (size_t)R * 4); F::load(ry_, child_aff + (size_t)R * 4 + 2);
+  G::pt lo, ro;
+  G::load(lo, child_xyzz + (size_t)L * 128); G::load(ro, child_xyzz + (size_t)R * 128);
   bool panic = false;
-  if (aff_id(lx_, ly_) || aff_id(rx_, ry_)) {         // :340-342
+  if (G::is_identity(lo) || G::is_identity(ro)) {     // :340-342
     pl.mode = MODE_PRODUCT;
     rf_len(pl.la, pl.lb, ll.x, ll.y, rl.x, rl.y, panic);
   } else {
     pl.mode = MODE_DIVIDE;
     // line through -L.out and -R.out (:344); equal points: through -L.out and c = -((-L.out) + (-R.out)) = this node's output
-    fe nly, nry, lx, ly, lz;
-    F::neg(nly, ly_); F::neg(nry, ry_);
-    if (!line_through(lx, ly, lz, lx_, nly, rx_, nry)) {
-      fe cx, cy; F::load(cx, node_aff + (size_t)k * 4); F::load(cy, node_aff + (size_t)k * 4 + 2);
-      line_through(lx, ly, lz, lx_, nly, cx, cy);
+    Hom ha, hb;
+    hom_of(ha, lo); hom_of(hb, ro);
+    F::neg(ha.y, ha.y); F::neg(hb.y, hb.y);
+    fe lx, ly, lz;
+    if (!line_through_hom(lx, ly, lz, ha, hb)) {
+      G::pt c; G::load(c, node_xyzz + (size_t)k * 128);
+      Hom hc; hom_of(hc, c);
+      line_through_hom(lx, ly, lz, ha, hc);
     }
-    st(pl.c0, lz); st(pl.c1, lx); st(pl.d0, ly); st(pl.lx, lx_); st(pl.rx, rx_);
+    st(pl.c0, lz); st(pl.c1, lx); st(pl.d0, ly);
+    st(pl.lX, lo.x); st(pl.lZZ, lo.zz); st(pl.rX, ro.x); st(pl.rZZ, ro.zz);
     u32 ta, tb, na, nb;
     rf_len(ta, tb, rl.x, rl.y, 2, 1, panic);          // b.wtns * linefunc
     rf_len(na, nb, ll.x, ll.y, ta, tb, panic);        // a.wtns * (..)
@@ -299,9 +337,9 @@ __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const 
   const size_t per = (size_t)nnodes << logN;
   u32* sLa = buf + (((size_t)k << logN)) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
   fe cb, ninv, cg; ld(cb, consts); ld(ninv, consts + 8); ld(cg, consts + 16);
-  fe c0, c1, d0, lxx, rxx;
+  fe c0, c1, d0, lX, lZZ, rX, rZZ;
   const bool divide = pl.mode == MODE_DIVIDE;
-  if (divide) { ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0); ld(lxx, pl.lx); ld(rxx, pl.rx); }
+  if (divide) { ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0); ld(lX, pl.lX); ld(lZZ, pl.lZZ); ld(rX, pl.rX); ld(rZZ, pl.rZZ); }
   // pass 1: numerators into the L.a / L.b slots, running product of the denominators into the R.a slot
   fe run; F::set_one(run);
   for (u32 i = i0; i < i1; i++) {
@@ -316,7 +354,7 @@ __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const 
       F::mul(tB, Ra, d0); F::mul(t, Rb, l); F::add(tB, tB, t);                        // R.a d0 + R.b l
       F::mul(A, La, tA); F::mul(t, Lb, tB); F::mul(t, t, s); F::add(A, A, t);
       F::mul(Bv, La, tB); F::mul(t, Lb, tA); F::add(Bv, Bv, t);
-      fe den; F::sub(t, x, lxx); F::sub(u, x, rxx); F::mul(den, t, u);
+      fe den; F::mul(t, lZZ, x); F::sub(t, t, lX); F::mul(u, rZZ, x); F::sub(u, u, rX); F::mul(den, t, u);   // (ZZ_L x - X_L)(ZZ_R x - X_R)
       if (F::is_zero(den)) { atomicOr(&stats[STAT_ZERODEN], 1u); F::set_one(den); }
       st(sRa + (size_t)i * 8, run);                                      // prefix product before this element
       st(sRb + (size_t)i * 8, den);
@@ -330,7 +368,7 @@ __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const 
   }
   if (!divide) return;
   // pass 2: Montgomery's trick backwards
-  fe inv; F::inv(inv, run);
+  fe inv; inv_fast(inv, run);
   for (u32 i = i1; i-- > i0;) {
     fe pref, den, di, A, Bv;
     ld(pref, sRa + (size_t)i * 8); ld(den, sRb + (size_t)i * 8);

@@ -1117,3 +1117,25 @@ def test_compute_lhs_witness_full_return_value(ctx, base, n):
     for f, (got, exp) in enumerate(zip(fns, efns)):
         e = O.normalise(exp)
         assert (_from_mont(got[0], p), _from_mont(got[1], p)) == e, f
+
+
+def test_divisor_witness_2p20_vanishes_on_its_points(ctx):
+    """full size (the point count of configs[1]'s per-digit lists): 2^20 walk points k Q and minus their sum
+    (n (n + 1) / 2 Q); the size-independent property the reference asserts (randpoints_witness_test :661): the
+    witness vanishes on every point -- checked on a sample by Horner evaluation in Python integers"""
+    g = pyref.GRUMPKIN; p = g.fp
+    O = dv.DivisorOracle(g, None)
+    n = 1 << 20
+    q = cref.gen_points(g.cid, 2000, 1)[0]
+    dp = ctx.gen_walk(g.cid, q, n)
+    rows = np.zeros((n + 1, 8), np.uint64)
+    rows[:n] = dp.download(np.uint64).reshape(-1, 8)
+    qa = g.raw_to_affine(q.tobytes())
+    last = g.neg(g.mul(n * (n + 1) // 2 % g.order, qa))
+    rows[n] = np.frombuffer(g.affine_to_raw(last), np.uint64)
+    a, b, outp = ctx.divisor_witness(api.GRUMPKIN, rows, True, True)
+    assert not outp.any() and a.shape[0] + b.shape[0] >= n
+    w = (_from_mont(a, p), _from_mont(b, p))
+    for idx in (0, 1, 12345, n - 1, n):
+        assert O.rf_ev(w, O.from_affine(g.raw_to_affine(rows[idx].tobytes()))) == 0, idx
+    dp.free()
