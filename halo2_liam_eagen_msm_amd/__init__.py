@@ -10,4 +10,5 @@ from .api import (  # noqa: F401
     jacobian_to_canonical, jacobian_sum, logb_ceil, order, num_digits, id_by_digit, digit_by_id,
     Bases, Node, comm_unique_id, prepare_scalar_witness, table_entry_by_id, TooManyDigits, RefIndexOutOfBounds,
     RefArithmeticOverflow, ENTRY_DTYPE, SumNotIdentity, compute_divisor_witness, compute_divisor_witness_partial,
+    to_curve_x, y_from_x, slope, WouldNotTerminate,
 )

@@ -26,6 +26,8 @@ LEMSM_ERR_RCCL = 9
 LEMSM_ERR_INDEX_OUT_OF_BOUNDS = 10
 LEMSM_ERR_ARITH_OVERFLOW = 11
 LEMSM_ERR_SUM_NOT_IDENTITY = 12
+LEMSM_ERR_WOULD_NOT_TERMINATE = 13
+LEMSM_ERR_DIVISION_BY_ZERO = 14
 LEMSM_COMM_ID_BYTES = 128
 
 BN254_G1 = 0
@@ -54,6 +56,7 @@ SYMBOLS = [
     "lemsm_debug_msm_sharded_sim", "lemsm_debug_lhs_sharded_sim",
     "lemsm_prepare_scalar_witness_batch", "lemsm_table_entries",
     "lemsm_divisor_witness", "lemsm_divisor_witness_device", "lemsm_divisor_last_ntt", "lemsm_lhs_witness", "lemsm_debug_ntt",
+    "lemsm_to_curve_x", "lemsm_y_from_x", "lemsm_slope",
 ]
 
 
@@ -149,6 +152,9 @@ def load() -> ctypes.CDLL:
         "lemsm_divisor_last_ntt": (i, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
         "lemsm_lhs_witness": (i, [vp, i, u8p, u64p, sz, ctypes.c_uint8, u64p, u64p, sz, szp, i, szp]),
         "lemsm_debug_ntt": (i, [vp, u64p, u64p, sz, ctypes.c_uint32, i]),
+        "lemsm_to_curve_x": (i, [i, u64p, u64p]),
+        "lemsm_y_from_x": (i, [i, u64p, u64p, ctypes.POINTER(i)]),
+        "lemsm_slope": (i, [i, u64p, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -765,6 +765,47 @@ def table_entry_by_id(base: int, idx: int, curve="grumpkin", ctx: Optional[Conte
     return (ctx or default_context()).table_entries(curve, base, idx, 1)[0]
 
 
+class WouldNotTerminate(LemsmError):
+    """reference: to_curve_x's loop never changes x (src/config.rs:170-173): a non-residue spins forever"""
+
+
+def to_curve_x(c, curve="grumpkin") -> np.ndarray:
+    """src/config.rs:166-175: c (one field element, 4 raw Montgomery limbs of the curve's base field) itself when c^3 + b is a
+    square; WouldNotTerminate where the reference would loop forever"""
+    v = np.ascontiguousarray(c, np.uint64).reshape(4)
+    out = np.zeros(4, np.uint64)
+    rc = _lib.load().lemsm_to_curve_x(_curve_id(curve), _ptr(v), _ptr(out))
+    if rc == _lib.LEMSM_ERR_WOULD_NOT_TERMINATE:
+        raise WouldNotTerminate(rc, "to_curve_x: x^3 + b is not a square and the reference's loop never changes x")
+    if rc:
+        raise LemsmError(rc, "to_curve_x")
+    return out
+
+
+def y_from_x(x, curve="grumpkin") -> Tuple[np.ndarray, bool]:
+    """src/config.rs:177-182: (y, is_square) = sqrt_alt(x^3 + b) in the curve's base field (see include/lemsm.h for the root chosen)"""
+    v = np.ascontiguousarray(x, np.uint64).reshape(4)
+    out = np.zeros(4, np.uint64)
+    flag = ctypes.c_int(0)
+    rc = _lib.load().lemsm_y_from_x(_curve_id(curve), _ptr(v), _ptr(out), ctypes.byref(flag))
+    if rc:
+        raise LemsmError(rc, "y_from_x")
+    return out, bool(flag.value)
+
+
+def slope(xy, curve="grumpkin") -> np.ndarray:
+    """src/config.rs:184-187: (3 x^2 + a) / (2 y) of an affine point (8 limbs); ZeroDivisionError where the reference's
+    invert().unwrap() panics"""
+    v = np.ascontiguousarray(xy, np.uint64).reshape(8)
+    out = np.zeros(4, np.uint64)
+    rc = _lib.load().lemsm_slope(_curve_id(curve), _ptr(v), _ptr(out))
+    if rc == _lib.LEMSM_ERR_DIVISION_BY_ZERO:
+        raise ZeroDivisionError("slope: y == 0")
+    if rc:
+        raise LemsmError(rc, "slope")
+    return out
+
+
 def precompute_multiplicities(pt_jacobian, base: int, curve="grumpkin", ctx: Optional[Context] = None) -> np.ndarray:
     """[1*P, .., (base-1)*P] as Jacobian points, shape (base-1, 12)."""
     return (ctx or default_context()).precompute_multiplicities(curve, np.asarray(pt_jacobian).reshape(1, 12), base)[0]

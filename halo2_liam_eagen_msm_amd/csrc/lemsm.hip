@@ -1268,6 +1268,8 @@ const char* lemsm_strerror(int s) {
     case LEMSM_ERR_INDEX_OUT_OF_BOUNDS: return "index out of bounds";
     case LEMSM_ERR_ARITH_OVERFLOW: return "arithmetic overflow";
     case LEMSM_ERR_SUM_NOT_IDENTITY: return "points do not sum to the identity";
+    case LEMSM_ERR_WOULD_NOT_TERMINATE: return "the reference would loop forever";
+    case LEMSM_ERR_DIVISION_BY_ZERO: return "division by zero";
     default: return "unknown status";
   }
 }

@@ -66,7 +66,9 @@ enum lemsm_status {
   LEMSM_ERR_RCCL = 9,
   LEMSM_ERR_INDEX_OUT_OF_BOUNDS = 10,
   LEMSM_ERR_ARITH_OVERFLOW = 11,
-  LEMSM_ERR_SUM_NOT_IDENTITY = 12
+  LEMSM_ERR_SUM_NOT_IDENTITY = 12,
+  LEMSM_ERR_WOULD_NOT_TERMINATE = 13,
+  LEMSM_ERR_DIVISION_BY_ZERO = 14
 };
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -257,6 +259,19 @@ int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithm
 int lemsm_lhs_witness(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* pts_jacobian, size_t n,
                       uint8_t base, uint64_t out_carry[12], uint64_t* out_coeffs, size_t cap_coeffs, size_t* out_index,
                       int normalise, size_t* bad_index);
+
+/* ---- challenge post-processing helpers (src/config.rs:166-187) ------------------------ */
+/* Host-side (a handful of field operations each); field elements are raw Montgomery limbs of the BASE field of `curve`.
+   to_curve_x (:166-175): returns c itself when c^3 + b is a square; the reference's loop never changes x (:170-173), so
+   for a non-residue it spins forever: LEMSM_ERR_WOULD_NOT_TERMINATE.
+   y_from_x (:177-182): the second component of sqrt_alt(x^3 + b): a square root when there is one (*is_square = 1), else
+   sqrt(ROOT_OF_UNITY * (x^3 + b)) (*is_square = 0), as ff::Field::sqrt_alt specifies.  Which of the two roots: the one
+   Tonelli-Shanks seeded with ROOT_OF_UNITY produces (a^((p+1)/4) for p = 3 mod 4); the upstream source is not in the
+   reference tree, so the sign convention is parity-unpinned -- the other root is the negation.
+   slope (:184-187): 3 x^2 / (2 y); y == 0 is the reference's invert().unwrap() panic: LEMSM_ERR_DIVISION_BY_ZERO. */
+int lemsm_to_curve_x(int curve, const uint64_t c[4], uint64_t out_x[4]);
+int lemsm_y_from_x(int curve, const uint64_t x[4], uint64_t out_y[4], int* is_square);
+int lemsm_slope(int curve, const uint64_t xy[8], uint64_t out[4]);
 
 /* ---- precompute_multiplicities ------------------------------------------------------- */
 /* out[(k-1)] = k * pt for k = 1..base-1 (Jacobian), for each of n points:

@@ -123,3 +123,50 @@ def test_jacobian_sum_host():
             acc = curve.add(acc, p_)
         got = api.jacobian_sum(curve.cid, np.stack([jac(p_) for p_ in pts]))
         assert cref.jac_to_canonical(curve.cid, got) == curve.canonical(acc)
+
+
+# ------------------------------------------------------------------ challenge post-processing helpers
+def _mont(v, p):
+    return np.frombuffer(((v << 256) % p).to_bytes(32, "little"), np.uint64).copy()
+
+
+def _unmont(limbs, p):
+    return int.from_bytes(np.ascontiguousarray(limbs, np.uint64).tobytes(), "little") * pow(1 << 256, -1, p) % p
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_to_curve_x_y_from_x_slope(curve):
+    """src/config.rs:166-187 against big-integer arithmetic: to_curve_x returns its input when x^3 + b is a square and reports
+    the reference's endless loop otherwise; y_from_x is sqrt_alt (a root of x^3 + b, or of ROOT_OF_UNITY (x^3 + b) for a
+    non-residue); slope = 3 x^2 / (2 y) with the y = 0 panic as an error"""
+    p = curve.fp
+    # ROOT_OF_UNITY = g^t, t the odd part of p - 1, g the multiplicative generator halo2curves uses (3 for Fq, 7 for Fr)
+    t = p - 1
+    while t % 2 == 0:
+        t //= 2
+    root = pow(3 if curve.cid == 0 else 7, t, p)
+    rng = pyref.SplitMix64(3100 + curve.cid)
+    seen = {True: 0, False: 0}
+    for _ in range(60):
+        x = rng.next256() % p
+        rhs = (x * x * x + curve.b) % p
+        sq = rhs == 0 or pow(rhs, (p - 1) // 2, p) == 1
+        seen[sq] += 1
+        y, flag = api.y_from_x(_mont(x, p), curve.cid)
+        yv = _unmont(y, p)
+        assert flag == sq
+        assert yv * yv % p == (rhs if sq else root * rhs % p)
+        if sq:
+            assert _unmont(api.to_curve_x(_mont(x, p), curve.cid), p) == x
+            if yv:
+                s = api.slope(np.concatenate([_mont(x, p), y]), curve.cid)
+                assert _unmont(s, p) == 3 * x * x * pow(2 * yv, -1, p) % p
+        else:
+            with pytest.raises(api.WouldNotTerminate):
+                api.to_curve_x(_mont(x, p), curve.cid)
+    assert seen[True] > 10 and seen[False] > 10
+    gx, gy = curve.gen
+    y, flag = api.y_from_x(_mont(gx, p), curve.cid)
+    assert flag and _unmont(y, p) in (gy, p - gy)
+    with pytest.raises(ZeroDivisionError):
+        api.slope(np.concatenate([_mont(gx, p), np.zeros(4, np.uint64)]), curve.cid)
