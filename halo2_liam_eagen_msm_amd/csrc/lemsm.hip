@@ -99,7 +99,7 @@ struct lemsm_ctx {
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0;
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -1246,6 +1246,41 @@ __global__ __launch_bounds__(256) void k_gen_walk(const uint4* __restrict__ q_af
   }
 }
 
+// optional input validation (option "validate_points"): every affine point is (0,0) or satisfies y^2 = x^3 + b
+template <class F>
+__global__ __launch_bounds__(256) void k_validate_points(const uint4* __restrict__ pts, u32 n, int bcoef /* +3 or -17 */, u32* __restrict__ err) {
+  u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  typedef typename F::fe fe;
+  fe x, y; F::load(x, pts + (size_t)j * 4); F::load(y, pts + (size_t)j * 4 + 2);
+  if (F::is_zero(x) && F::is_zero(y)) return;
+  fe one, b, t, l, r; F::set_one(one); F::set_zero(b);
+  int m = bcoef < 0 ? -bcoef : bcoef;
+  for (int bit = 5; bit >= 0; bit--) { F::add(b, b, b); if ((m >> bit) & 1) F::add(b, b, one); }
+  if (bcoef < 0) F::neg(b, b);
+  F::sqr(l, y); F::sqr(t, x); F::mul(r, t, x); F::add(r, r, b);
+  if (!F::eq(l, r)) atomicMin(err, j);
+}
+
+int validate_points(lemsm_ctx* ctx, int curve, const void* d_points, size_t n) {
+  if (!ctx->opt_validate_points || n == 0) return LEMSM_OK;
+  int rc = reserve(ctx, ctx->in_aux, 256); if (rc) return rc;
+  u32 init = 0xffffffffu;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_aux.p, &init, 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t s0 = 0; s0 < n; s0 += (size_t)1 << 30) {
+    u32 cnt = (u32)std::min((size_t)1 << 30, n - s0);
+    const uint4* p = (const uint4*)((const char*)d_points + s0 * 64);
+    if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_validate_points<FqDev>), dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, p, cnt, 3, (u32*)ctx->in_aux.p);
+    else hipLaunchKernelGGL((k_validate_points<FrDev>), dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, p, cnt, -17, (u32*)ctx->in_aux.p);
+    u32 bad = 0xffffffffu;
+    HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->in_aux.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != 0xffffffffu) { ctx->bad_index = s0 + bad; return fail(ctx, LEMSM_ERR_BAD_ARG, "point is not on the curve (option validate_points)"); }
+  }
+  return LEMSM_OK;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -1324,6 +1359,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
   else if (!strcmp(name, "xcd_windows")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_xcd_windows = value; }
+  else if (!strcmp(name, "validate_points")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_validate_points = value; }
   else if (!strcmp(name, "entry_ring")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_entry_ring = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
   else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
@@ -1384,6 +1420,7 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   int rc = check_curve(ctx, curve); if (rc) return rc;
   if (n == 0) { memset(out, 0, 96); return LEMSM_OK; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!(ctx->host_stage && ctx->host_stage->h_points)) { rc = validate_points(ctx, curve, d_points, n); if (rc) return rc; }
   MsmPlan mp = make_msm_plan(ctx, curve, n);
   std::vector<host::pt> recs;
   ctx->want_raw_records = true;
@@ -1404,6 +1441,10 @@ int lemsm_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t*
   rc = reserve(ctx, ctx->in_s, n * 32); if (rc) return rc;
   rc = reserve(ctx, ctx->in_p, n * 64); if (rc) return rc;
   HostStage hs{scalars, points, (char*)ctx->in_s.p, (char*)ctx->in_p.p};
+  if (ctx->opt_validate_points) {   // validated inputs: the points are uploaded whole and checked before any slab runs
+    HIPCHK(ctx, hipMemcpy(ctx->in_p.p, points, n * 64, hipMemcpyHostToDevice));
+    hs.h_points = nullptr;
+  }
   ctx->host_stage = &hs;
   rc = lemsm_msm_device(ctx, curve, ctx->in_s.p, ctx->in_p.p, n, out);
   ctx->host_stage = nullptr;
@@ -1557,6 +1598,7 @@ int lemsm_lhs_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const
   int rc = check_curve(ctx, curve); if (rc) return rc;
   LhsPlan lp; rc = make_lhs_plan(curve, base, lp); if (rc) return fail(ctx, rc, "base must be in 3..=255");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  rc = validate_points(ctx, curve, d_points, n); if (rc) return rc;
   std::vector<host::pt> recs;
   rc = lhs_partial_dispatch(ctx, curve, d_scalars, d_points, n, lp, 0, lp.d, recs, bad_index);
   if (rc) return rc;

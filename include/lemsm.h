@@ -96,7 +96,10 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    "seg_records" (edge records per thread at the first reduction level, 0 = auto = 8),
    "abi_points" (lazy arithmetic: 1 = convert the points to the kernels' domain in a pass of their
    own, 2 = let the accumulation consume them as passed in, 0 = choose by segment length and window
-   count). */
+   count), "validate_points" (1: lemsm_msm*, lemsm_lhs_msm* check y^2 = x^3 + b for every non-identity input point
+   before any work and return LEMSM_ERR_BAD_ARG with the index in lemsm_last_bad_index; 0, the default, trusts the
+   caller like the reference's from_raw_bytes_unchecked does -- the hot kernel tests y alone for the identity,
+   so an invalid (x != 0, y == 0) input would otherwise be skipped silently). */
 int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value);
 /* Device-time (ms, from HIP events on the context's stream) of the last MSM call: whole
    pipeline in [0], the dominant accumulate kernel in [1], its launch count in [2]. */
@@ -292,7 +295,7 @@ int lemsm_jacobian_to_canonical(int curve, const uint64_t jacobian[12], uint8_t 
 /* Sum of `count` Jacobian points on the host (identity for count == 0).  Combines the partial
    results of an MSM whose POINTS were split across callers / GPUs -- the step halo2's
    best_multiexp performs over its per-thread chunk results (`results.iter().fold(identity, a + b)`
-   in the halo2_proofs dependency the reference calls at src/argument_witness_calc.rs:223). */
+   in the halo2_proofs dependency the reference calls at src/argument_witness_calc.rs:144). */
 int lemsm_jacobian_sum(int curve, const uint64_t* jacobian, size_t count, uint64_t out[12]);
 /* Device memory helpers so that non-HIP hosts can stage resident inputs. */
 int lemsm_device_alloc(lemsm_ctx* ctx, size_t bytes, void** out);

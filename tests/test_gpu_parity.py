@@ -1139,3 +1139,30 @@ def test_divisor_witness_2p20_vanishes_on_its_points(ctx):
     for idx in (0, 1, 12345, n - 1, n):
         assert O.rf_ev(w, O.from_affine(g.raw_to_affine(rows[idx].tobytes()))) == 0, idx
     dp.free()
+
+
+def test_validate_points_option(ctx):
+    """option validate_points: an input that is not on the curve (here y + 1, and the (x != 0, y == 0) shape the hot kernel
+    would silently take for the identity) is refused with its index; off (the default) the caller is trusted like the
+    reference's from_raw_bytes_unchecked"""
+    curve = pyref.BN254_G1
+    n = 5000
+    pts = cref.gen_points(curve.cid, 2101, n); sc = cref.gen_scalars(curve.cid, 2102, n)
+    good = canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    bad = pts.copy(); bad[3210, 4] += np.uint64(1)
+    bad2 = pts.copy(); bad2[77, 4:] = 0
+    ctx.set_option("validate_points", 1)
+    try:
+        assert canon(curve, ctx.msm(curve.cid, sc, pts)) == good
+        for arr, idx in ((bad, 3210), (bad2, 77)):
+            with pytest.raises(api.LemsmError) as ei:
+                ctx.msm(curve.cid, sc, arr)
+            assert ei.value.status == 6 and ctx.lib.lemsm_last_bad_index(ctx.h) == idx
+            dp = ctx.to_device(arr); ds = ctx.to_device(sc)
+            with pytest.raises(api.LemsmError):
+                ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+            with pytest.raises(api.LemsmError):
+                ctx.lhs_msm_device(curve.cid, ds.ptr, dp.ptr, n, 16)
+    finally:
+        ctx.set_option("validate_points", 0)
+    ctx.msm(curve.cid, sc, bad2)      # unchecked: no error (the point is skipped)
