@@ -11,4 +11,5 @@ template __global__ void lemsm::k_accum1<G, 4>(GroupPlan, const u32*, const u32*
 template __global__ void lemsm::k_segreduce<G>(u32, u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
+template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*);
 template __global__ void lemsm::k_convert_points<Field29<Fq29Params>>(const uint4*, uint4*, u32);

@@ -7,3 +7,4 @@ template __global__ void lemsm::k_accum1<G, 4>(GroupPlan, const u32*, const u32*
 template __global__ void lemsm::k_segreduce<G>(u32, u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);
 template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
+template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*);

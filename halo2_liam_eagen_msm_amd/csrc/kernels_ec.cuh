@@ -280,12 +280,28 @@ __global__ __launch_bounds__(256) void k_segwave(u32 R, u32 scaled, const u32* _
 // applied to every window.  Arena offsets are in points (128 B); src indices >= src_valid
 // read as the identity (padding of non-power-of-two bucket counts).
 // ------------------------------------------------------------------------------------
+// (layout of CopyTask in kernels.cuh)
+struct CopyTaskPod { u32 src_off, src_wstride, dst_off, dst_wstride, src_valid_idx, src_idx; };
+
 struct PyrTask {
   u32 src_off, src_wstride;   // per-window base = src_off + w * src_wstride
   u32 dst_off, dst_wstride;
   u32 stride, phase, count, src_valid;
   u32 src_scaled, pad_[3];    // source is bucket_sum[] in the scaled form: convert on load
 };
+
+// one item of one task: dst[i] = src[(2i) stride + phase] + src[(2i+1) stride + phase] for window w
+template <class G>
+__device__ __forceinline__ void pyr_item(const PyrTask& tk, u32 w, u32 i, char* __restrict__ arena) {
+  u32 ia = (2 * i) * tk.stride + tk.phase, ib = (2 * i + 1) * tk.stride + tk.phase;
+  const char* src = arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride) * G::PT_BYTES;
+  typename G::pt a, b;
+  if (ia < tk.src_valid) G::load(a, src + (size_t)ia * G::PT_BYTES); else G::set_identity(a);
+  if (ib < tk.src_valid) G::load(b, src + (size_t)ib * G::PT_BYTES); else G::set_identity(b);
+  if (tk.src_scaled) { G::unscale(a); G::unscale(b); }
+  G::add(a, b);
+  G::store(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride + i) * G::PT_BYTES, a);
+}
 
 template <class G>
 __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tasks, u32 ntasks, u32 nwin,
@@ -298,14 +314,41 @@ __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tas
   u32 w = rem / max_count, i = rem - w * max_count;
   PyrTask tk = tasks[ti];
   if (i >= tk.count) return;
-  u32 ia = (2 * i) * tk.stride + tk.phase, ib = (2 * i + 1) * tk.stride + tk.phase;
-  const char* src = arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride) * G::PT_BYTES;
-  typename G::pt a, b;
-  if (ia < tk.src_valid) G::load(a, src + (size_t)ia * G::PT_BYTES); else G::set_identity(a);
-  if (ib < tk.src_valid) G::load(b, src + (size_t)ib * G::PT_BYTES); else G::set_identity(b);
-  if (tk.src_scaled) { G::unscale(a); G::unscale(b); }
-  G::add(a, b);
-  G::store(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride + i) * G::PT_BYTES, a);
+  pyr_item<G>(tk, w, i, arena);
+}
+
+// The last steps of the pyramid in ONE launch: from the step where a window's whole step fits a few passes of one
+// 1024-thread block, the steps are only latency (one XYZZ addition deep each, ~7 us) and a launch per step costs
+// 3-4x that.  One block per window walks the remaining steps with a block barrier between them (a step's
+// tasks read what the previous step of the SAME window wrote: workgroup-scope visibility suffices), then copies
+// U_{L-1} = A^{L-1}[1] into place (what k_copy_points did in a launch of its own).
+// steps: [first, last]; task t of step s is tasks[step_off[s - first] + t].
+struct PyrTailArgs { u32 first, last, max_count[20], step_off[21]; };
+template <class G>
+__global__ __launch_bounds__(1024) void k_pyramid_tail(const PyrTask* __restrict__ tasks, PyrTailArgs ta, const CopyTaskPod* __restrict__ copy,
+                                                       u32 do_copy, char* __restrict__ arena) {
+  const u32 w = blockIdx.x, tid = threadIdx.x;
+  for (u32 s = ta.first; s <= ta.last; s++) {
+    const u32 k = s - ta.first;
+    const u32 nt = ta.step_off[k + 1] - ta.step_off[k], mc = ta.max_count[k];
+    for (u32 it = tid; it < nt * mc; it += 1024) {
+      const u32 ti = it / mc, i = it - ti * mc;
+      PyrTask tk = tasks[ta.step_off[k] + ti];
+      if (i < tk.count) pyr_item<G>(tk, w, i, arena);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (do_copy) {
+    const u32 wpp = G::PT_BYTES / 16;
+    if (tid < wpp) {
+      CopyTaskPod tk = *copy;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tk.src_idx < tk.src_valid_idx)
+        v = reinterpret_cast<const uint4*>(arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride + tk.src_idx) * G::PT_BYTES)[tid];
+      reinterpret_cast<uint4*>(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride) * G::PT_BYTES)[tid] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUN
 #define LEMSM_EXTERN_G(G)                                                                                   \
   extern template __global__ void lemsm::k_segreduce<G>(u32, u32, u32, const u32*, const char*, char*, u32*, char*); \
   extern template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);                     \
-  extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
+  extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*); \
+  extern template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*);
 #define LEMSM_EXTERN_ACC(G, W) \
   extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
 LEMSM_EXTERN_G(GqStrict) LEMSM_EXTERN_G(GrStrict) LEMSM_EXTERN_G(GqLazy) LEMSM_EXTERN_G(GrLazy)
@@ -99,7 +100,7 @@ struct lemsm_ctx {
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0;
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -548,17 +549,33 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       std::swap(ik, ok); std::swap(ip, op);
     }
   }
-  // bucket reduction pyramid
+  // bucket reduction pyramid: one launch per step while a step is wide, then all remaining steps (and the copy of
+  // U_{L-1}) in one launch of one block per window (k_pyramid_tail)
   {
     size_t toff = 0;
-    for (u32 s = 1; s <= L; s++) {
+    u32 first_fused = L + 1;
+    if (ctx->opt_pyr_fuse != 1)
+      for (u32 s = 1; s <= L; s++) {
+        bool fits = true;
+        for (u32 q = s; q <= L; q++) if ((size_t)pp.steps[q - 1].size() * pp.step_max_count[q - 1] > 2048) fits = false;
+        if (fits && L - s + 1 <= 20) { first_fused = s; break; }
+      }
+    for (u32 s = 1; s <= L && s < first_fused; s++) {
       auto& tasks = pp.steps[s - 1];
       u32 maxc = pp.step_max_count[s - 1];
       size_t threads = (size_t)tasks.size() * maxc * gw;
       hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, d_tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
       toff += tasks.size();
     }
-    if (!(L == 1 && abi)) {
+    const bool need_copy = !(L == 1 && abi);
+    if (first_fused <= L) {
+      PyrTailArgs ta; memset(&ta, 0, sizeof ta);
+      ta.first = first_fused; ta.last = L;
+      u32 o = (u32)toff;
+      for (u32 s = first_fused; s <= L; s++) { ta.step_off[s - first_fused] = o; ta.max_count[s - first_fused] = pp.step_max_count[s - 1]; o += (u32)pp.steps[s - 1].size(); }
+      ta.step_off[L - first_fused + 1] = o;
+      hipLaunchKernelGGL((k_pyramid_tail<G>), dim3(gw), dim3(1024), 0, st, (const PyrTask*)d_tasks, ta, (const CopyTaskPod*)d_copy, need_copy ? 1u : 0u, w.arena);
+    } else if (need_copy) {
       u32 cthreads = gw * (u32)(ptb / 16);
       hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, d_copy, 1u, gw, (u32)ptb, w.arena);
     }
@@ -1359,6 +1376,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
   else if (!strcmp(name, "xcd_windows")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_xcd_windows = value; }
+  else if (!strcmp(name, "pyr_fuse")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_fuse = value; }
   else if (!strcmp(name, "validate_points")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_validate_points = value; }
   else if (!strcmp(name, "entry_ring")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_entry_ring = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
