@@ -26,3 +26,15 @@ for bits in (24, 21, 20, 19, 0):
     t1 = time.perf_counter(); ctx.msm_device(0, ds.ptr, dp.ptr, n); dd = time.perf_counter() - t1
     print("2^%d host_slab_bits=%d: host-pointer entry %.1f ms (%.0f Mpairs/s, %.1f GB/s of input) | device-resident entry %.1f ms"
           % (logn, bits, best * 1e3, n / best / 1e6, n * 96 / best / 1e9, dd * 1e3), flush=True)
+
+# resident bases: the points uploaded once (lemsm_bases_upload), only the scalars cross PCIe per call
+ctx.set_option("host_slab_bits", 0)
+bases = ctx.bases_upload(0, pts)
+for bits in (0, 22, 21, 20):
+    ctx.set_option("host_slab_bits", bits)
+    best = 1e9
+    for it in range(4):
+        t0 = time.perf_counter(); out = ctx.msm_with_bases(bases, sc); dt = time.perf_counter() - t0
+        assert jacobian_to_canonical(0, out) == ref
+        best = min(best, dt)
+    print("2^%d host_slab_bits=%d: lemsm_msm_with_bases (scalars from host, bases resident) %.1f ms (%.0f Mpairs/s)" % (logn, bits, best * 1e3, n / best / 1e6), flush=True)
