@@ -188,6 +188,10 @@ u32 choose_c(const lemsm_ctx* ctx, size_t n) {
 u32 host_slab_log(const lemsm_ctx* ctx, size_t n) {
   u32 lg = 0; while (((size_t)2 << lg) <= n) lg++;   // floor(log2 n)
   u32 auto_log = std::min(21u, std::max(19u, lg >= 2 ? lg - 2 : 0u));
+  // resident bases (lemsm_msm_with_bases): only 32 B per pair cross PCIe, the upload of a slab takes half the time its
+  // kernels do, so fewer, larger slabs win (each slab pays its own sort + tail): 2^22 measured best at 2^24
+  // (profiles/r02/m_host_path_2p24.txt)
+  if (ctx->host_stage && !ctx->host_stage->h_points) auto_log = std::min(22u, std::max(19u, lg >= 2 ? lg - 2 : 0u));
   return std::min<u32>(MAX_SLAB_LOG, ctx->opt_host_slab_bits ? (u32)ctx->opt_host_slab_bits : auto_log);
 }
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Static ISA budget of a kernel's hot loop: instruction classes per loop iteration.
 
-    python tools/isa_budget.py <file.s> <kernel-name-regex>
+    python tools/isa_budget.py <file.s> <kernel-name-regex> [--whole]
+
+--whole: histogram of the whole kernel (for straight-line bodies such as tools/ubench/madd_body.hip).
 
 Reads hipcc -S output, finds the kernel, takes its largest innermost loop (a backward branch to a label with the
 most instructions in between) and prints a histogram by class -- the table DESIGN.md's "instruction budget of one
@@ -41,7 +43,7 @@ def classify(op):
 def main():
     path, pat = sys.argv[1], re.compile(sys.argv[2])
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.endswith(":") or ": ;" in l if pat.search(l.split(":")[0]) and l.startswith("_Z"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and ":" in l and pat.search(l.split(":")[0]))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end]
     labels = {}
@@ -67,6 +69,8 @@ def main():
                 if best is None or span[1] - span[0] > best[1] - best[0]:
                     best = span
     print("kernel:", body[0].split(":")[0][:120])
+    if "--whole" in sys.argv:
+        best = (0, len(instrs) - 1)
     print("static instructions in kernel: %d; largest loop: %d instructions" % (len(instrs), best[1] - best[0] + 1))
     cnt = collections.Counter(classify(op) for _, op, _ in instrs[best[0]:best[1] + 1])
     tot = sum(cnt.values())
