@@ -44,7 +44,7 @@ enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_WORDS = 4 };
 
 // what k_plan decides for one node of the next level
 struct Plan {
-  u32 mode, la, lb, pad;
+  u32 mode, la, lb, child0;  // child0: global index (level below) of the left child; the right one is child0 + 1
   u32 c0[8], c1[8], d0[8];   // line(-L.out, -R.out) = (c0 + c1 x) + y d0      (from_line(lx, ly, lz): a = [lz, lx], b = [ly], :244-246)
   u32 lX[8], lZZ[8], rX[8], rZZ[8];   // L.out, R.out as X / ZZ: the two kate_div points (:351-357) divide by (x - X/ZZ); here by
                                       // (ZZ x - X), a scalar multiple -- the witness is only defined up to a scalar anyway
@@ -107,30 +107,51 @@ __device__ __forceinline__ bool line_through_hom(fe& lx, fe& ly, fe& lz, const H
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// A FOREST of T independent trees runs as one batch (compute_lhs_witness builds d of them, one per digit position:
+// one forest costs the launches of one tree).  Tree t owns nodes [off[t], off[t+1]) of a level (points of the
+// concatenated input at the leaves); node k of a tree merges its children 2k and 2k+1 of the level below, a lone
+// last child passes through, and a tree that is finished (one node) passes through until the tallest one is.
+// ---------------------------------------------------------------------------------------------------------
+struct Forest {
+  const u32* off_child;   // T + 1 offsets of the level below (points, for the leaves)
+  const u32* off_node;    // T + 1 offsets of this level
+  u32 T;
+};
+// global node g -> (first child c0 as a global index of the level below, number of children 1 or 2 [0: none])
+__device__ __forceinline__ void locate(const Forest& f, u32 g, u32& c0, u32& nch) {
+  u32 lo = 0, hi = f.T;                      // largest t with off_node[t] <= g
+  while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (f.off_node[mid] <= g) lo = mid; else hi = mid; }
+  const u32 k = g - f.off_node[lo];
+  const u32 cb = f.off_child[lo], cn = f.off_child[lo + 1] - cb;
+  c0 = cb + 2 * k;
+  nch = (2 * k + 1 < cn) ? 2u : (2 * k < cn ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // points: node outputs stay in XYZZ from level to level (no inversion anywhere in the tree)
 // ---------------------------------------------------------------------------------------------------------
 // leaves: sum[k] = -(pts[2k] + pts[2k+1]) (a lone last point: -pts[2k]) as XYZZ               (:321, :330)
-__global__ __launch_bounds__(256) void k_leaf_sum(const uint4* __restrict__ pts, u32 n, u32 nleaf, char* __restrict__ out_xyzz) {
-  u32 k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nleaf) return;
+__global__ __launch_bounds__(256) void k_leaf_sum(const uint4* __restrict__ pts, Forest f, u32 nleaf, char* __restrict__ out_xyzz) {
+  u32 g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nleaf) return;
+  u32 c0, nch; locate(f, g, c0, nch);
   G::pt acc; G::set_identity(acc);
-  for (u32 t = 0; t < 2; t++) {
-    u32 j = 2 * k + t;
-    if (j >= n) break;
-    fe x, y; F::load(x, pts + (size_t)j * 4); F::load(y, pts + (size_t)j * 4 + 2);
+  for (u32 t = 0; t < nch; t++) {
+    fe x, y; F::load(x, pts + (size_t)(c0 + t) * 4); F::load(y, pts + (size_t)(c0 + t) * 4 + 2);
     if (!aff_id(x, y)) G::madd(acc, x, y);
   }
   F::neg(acc.y, acc.y);
-  G::store(out_xyzz + (size_t)k * 128, acc);
+  G::store(out_xyzz + (size_t)g * 128, acc);
 }
 
 // inner nodes: out[k] = child[2k] + child[2k+1] (a lone child passes through)   (:335)
-__global__ __launch_bounds__(256) void k_merge_sum(const char* __restrict__ child_xyzz, u32 nchild, u32 nnodes, char* __restrict__ out_xyzz) {
-  u32 k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nnodes) return;
-  G::pt acc; G::load(acc, child_xyzz + (size_t)(2 * k) * 128);
-  if (2 * k + 1 < nchild) { G::pt q; G::load(q, child_xyzz + (size_t)(2 * k + 1) * 128); G::add(acc, q); }
-  G::store(out_xyzz + (size_t)k * 128, acc);
+__global__ __launch_bounds__(256) void k_merge_sum(const char* __restrict__ child_xyzz, Forest f, u32 nnodes, char* __restrict__ out_xyzz) {
+  u32 g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nnodes) return;
+  u32 c0, nch; locate(f, g, c0, nch);
+  G::pt acc; G::load(acc, child_xyzz + (size_t)c0 * 128);
+  if (nch == 2) { G::pt q; G::load(q, child_xyzz + (size_t)(c0 + 1) * 128); G::add(acc, q); }
+  G::store(out_xyzz + (size_t)g * 128, acc);
 }
 
 // XYZZ -> affine, Montgomery's trick over KB points per thread (prefix products in scratch[k][thread]); identity -> (0,0)
@@ -164,15 +185,20 @@ __global__ __launch_bounds__(256) void k_to_affine(const char* __restrict__ xyzz
 // ---------------------------------------------------------------------------------------------------------
 // leaves: the line of every pair (from_pair :328-331, from_point :319-322, empty :324-326)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_leaf_lines(const uint4* __restrict__ pts, u32 n, u32 nleaf, const char* __restrict__ out_xyzz,
+__global__ __launch_bounds__(256) void k_leaf_lines(const uint4* __restrict__ pts, Forest f, u32 nleaf, const char* __restrict__ out_xyzz,
                                                     u32* __restrict__ A, u32* __restrict__ B, u32 capA, u32 capB, uint2* __restrict__ lens) {
   u32 k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nleaf) return;
+  u32 c0, nch; locate(f, k, c0, nch);
   fe x1, y1, x2, y2, zero, one;
   F::set_zero(zero); F::set_one(one);
-  F::load(x1, pts + (size_t)(2 * k) * 4); F::load(y1, pts + (size_t)(2 * k) * 4 + 2);
-  const bool lone = 2 * k + 1 >= n;
-  if (lone) { x2 = zero; y2 = zero; } else { F::load(x2, pts + (size_t)(2 * k + 1) * 4); F::load(y2, pts + (size_t)(2 * k + 1) * 4 + 2); }
+  if (nch == 0) {                         // the single leaf of an EMPTY list: (RegularFunction::from_const(ONE), identity)  :455
+    st(A + (size_t)k * capA * 8, one); lens[k] = make_uint2(1, 0);
+    return;
+  }
+  F::load(x1, pts + (size_t)c0 * 4); F::load(y1, pts + (size_t)c0 * 4 + 2);
+  const bool lone = nch < 2;
+  if (lone) { x2 = zero; y2 = zero; } else { F::load(x2, pts + (size_t)(c0 + 1) * 4); F::load(y2, pts + (size_t)(c0 + 1) * 4 + 2); }
   const bool id1 = aff_id(x1, y1), id2 = aff_id(x2, y2);
   u32* a = A + (size_t)k * capA * 8; u32* b = B + (size_t)k * capB * 8;
   fe lx, ly, lz;
@@ -213,17 +239,18 @@ __device__ __forceinline__ void rf_len(u32& la, u32& lb, u32 a1, u32 b1, u32 a2,
   la = max(aa, bbs); lb = max(ab, ba);
 }
 
-__global__ __launch_bounds__(256) void k_plan(const char* __restrict__ child_xyzz, const uint2* __restrict__ child_lens, u32 nchild, u32 nnodes,
+__global__ __launch_bounds__(256) void k_plan(const char* __restrict__ child_xyzz, const uint2* __restrict__ child_lens, Forest f, u32 nnodes,
                                               const char* __restrict__ node_xyzz, Plan* __restrict__ plan, u32* __restrict__ stats) {
   u32 k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nnodes) return;
-  Plan pl; pl.pad = 0;
-  const u32 L = 2 * k, R = 2 * k + 1;
+  Plan pl;
+  u32 c0, nch; locate(f, k, c0, nch);
+  pl.child0 = c0;
+  const u32 L = c0, R = c0 + 1;
   uint2 ll = child_lens[L];
-  if (R >= nchild) {                                  // MaybePair::Unit: passes through unchanged (:363-366)
+  if (nch < 2) {                                      // MaybePair::Unit: passes through unchanged (:363-366)
     pl.mode = MODE_PASS; pl.la = ll.x; pl.lb = ll.y;
     plan[k] = pl;
-    atomicMax(&stats[STAT_MAXLEN], max(ll.x, ll.y));
     return;
   }
   uint2 rl = child_lens[R];
@@ -304,7 +331,7 @@ __global__ __launch_bounds__(256) void k_load(const u32* __restrict__ cA, const 
   const u32 k = (u32)(rem >> logN), i = (u32)rem & ((1u << logN) - 1);
   fe v; F::set_zero(v);
   if (plan[k].mode != MODE_PASS) {
-    const u32 c = 2 * k + (q >> 1);
+    const u32 c = plan[k].child0 + (q >> 1);
     const uint2 cl = child_lens[c];
     bool have = false;
     if (q & 1) { if (i < cl.y) { ld(v, cB + ((size_t)c * ccapB + i) * 8); have = true; } }
@@ -392,12 +419,12 @@ __global__ __launch_bounds__(256) void k_store(const u32* __restrict__ buf, cons
   const size_t per = (size_t)nnodes << logN;
   fe v;
   if (i < pl.la) {
-    if (pl.mode == MODE_PASS) ld(v, cA + ((size_t)(2 * k) * ccapA + i) * 8);
+    if (pl.mode == MODE_PASS) ld(v, cA + ((size_t)pl.child0 * ccapA + i) * 8);
     else { ld(v, buf + (((size_t)k << logN) + i) * 8); if (i) { fe g; ld(g, GI + (size_t)i * 8); F::mul(v, v, g); } }
     st(nA + ((size_t)k * capA + i) * 8, v);
   }
   if (i < pl.lb) {
-    if (pl.mode == MODE_PASS) ld(v, cB + ((size_t)(2 * k) * ccapB + i) * 8);
+    if (pl.mode == MODE_PASS) ld(v, cB + ((size_t)pl.child0 * ccapB + i) * 8);
     else { ld(v, buf + (per + ((size_t)k << logN) + i) * 8); if (i) { fe g; ld(g, GI + (size_t)i * 8); F::mul(v, v, g); } }
     st(nB + ((size_t)k * capB + i) * 8, v);
   }
@@ -419,6 +446,15 @@ __global__ __launch_bounds__(256) void k_scale(u32* __restrict__ p, u32 cnt, con
   if (i >= cnt) return;
   fe s, v; ld(s, scale); ld(v, p + (size_t)i * 8); F::mul(v, v, s); st(p + (size_t)i * 8, v);
 }
+// the same for the T roots of a forest: node t's part (la or lb coefficients at stride cap) times scale[t]
+__global__ __launch_bounds__(256) void k_scale_roots(u32* __restrict__ p, u32 cap, const uint2* __restrict__ lens, u32 which, u32 T, const u32* __restrict__ scale) {
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (u64)T * cap) return;
+  const u32 t = (u32)(gid / cap), i = (u32)(gid - (u64)t * cap);
+  const uint2 l = lens[t];
+  if (i >= (which ? l.y : l.x)) return;
+  fe s, v; ld(s, scale + (size_t)t * 8); ld(v, p + ((size_t)t * cap + i) * 8); F::mul(v, v, s); st(p + ((size_t)t * cap + i) * 8, v);
+}
 
 // debug / KAT: plain forward or inverse transform of nseq sequences in natural order (bit reversal applied on the way in/out)
 __global__ __launch_bounds__(256) void k_bitrev_copy(const u32* __restrict__ in, u32* __restrict__ out, u32 nseq, u32 logN) {
@@ -434,6 +470,13 @@ __global__ __launch_bounds__(256) void k_lhs_flags(const uint8_t* __restrict__ d
   u32 j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   flags[j] = digitsT[(size_t)pos * n + j] ? 1u : 0u;
+}
+// nnz[pos] = number of scalars whose digit at position pos is non-zero (grid: (blocks over j, d))
+__global__ __launch_bounds__(256) void k_lhs_count(const uint8_t* __restrict__ digitsT, u32 n, u32* __restrict__ nnz) {
+  const u32 pos = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  const bool nzd = j < n && digitsT[(size_t)pos * n + j] != 0;
+  const unsigned long long b = __ballot(nzd);
+  if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&nnz[pos], (u32)__popcll(b));
 }
 __global__ __launch_bounds__(256) void k_lhs_gather(const uint8_t* __restrict__ digitsT, u32 n, u32 pos, u32 base, const u32* __restrict__ offs,
                                                     const uint4* __restrict__ table /* n x (base-1) affine */, u32 lead, uint4* __restrict__ out) {
