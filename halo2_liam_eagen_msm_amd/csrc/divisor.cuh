@@ -317,6 +317,80 @@ __global__ __launch_bounds__(256) void k_ntt_stage(u32* __restrict__ buf, u32 ns
   st(base + (size_t)i * 8, x); st(base + (size_t)j * 8, y);
 }
 
+// LDS-tiled form: one launch runs S consecutive stages on tiles of 1024 elements held in LDS (32 KB, limb-major so
+// that lanes touch consecutive banks), instead of one launch -- one trip through HBM -- per stage.
+//   lo == 0 : the tile is 1024 CONTIGUOUS elements and the S = min(logN, 10) stages with spans 2^(S-1)..1 run inside
+//             every aligned 2^S chunk of it (for logN < 10 a tile holds several whole sequences);
+//   lo  > 0 : stages with spans 2^(lo+S-1)..2^lo: a tile is 2^S positions 2^lo apart, TW = 1024 >> S neighbouring
+//             tiles side by side so that every access is a run of TW consecutive elements.
+// Forward (DIF) runs the strided passes from the top spans down, then the contiguous pass; inverse (DIT) the reverse.
+template <bool INV>
+__global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 total, u32 logN, u32 lo, u32 S,
+                                                  const u32* __restrict__ W, u32 log_half_max) {
+  __shared__ u32 sm[8][1024];
+  const u32 tid = threadIdx.x;
+  const u32 J = 1u << S;
+  const u32 TW = lo ? (1024u >> S) : 1u;            // lo > 0: TW tiles side by side; lo == 0: chunks of J inside 1024 contiguous
+  const u32 logTW = lo ? (10u - S) : 0u;
+  // element e of the tile -> global index
+  u64 base; u32 Lfull0 = 0;
+  if (lo == 0) base = (u64)blockIdx.x * 1024u;
+  else {
+    const u32 hi1 = lo + S;                          // a tile spans 2^hi1 positions
+    const u32 lgroups = 1u << (lo - logTW);          // groups of TW neighbouring low offsets
+    const u64 b = blockIdx.x;
+    const u32 Lg = (u32)(b % lgroups); const u64 rest = b / lgroups;   // rest = seq * (N >> hi1) + H
+    base = (rest << hi1) + ((u64)Lg << logTW);       // (seq * N + H * 2^hi1) + Lg * TW   [N is a multiple of 2^hi1]
+    Lfull0 = Lg << logTW;
+  }
+  auto gidx = [&](u32 e) -> u64 { return lo == 0 ? base + e : base + ((u64)(e >> logTW) << lo) + (e & (TW - 1)); };
+  // load
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 e = tid + 256u * q;
+    const u64 g = gidx(e);
+    fe v; F::set_zero(v);
+    if (g < total) ld(v, buf + g * 8);
+#pragma unroll
+    for (int l = 0; l < 8; l++) sm[l][e] = v.v[l];
+  }
+  __syncthreads();
+  for (u32 st_ = 0; st_ < S; st_++) {
+    const u32 ls = INV ? st_ : (S - 1 - st_);        // local span 2^ls (in tile positions j)
+    const u32 logm = lo + ls;                        // global span
+#pragma unroll
+    for (u32 q = 0; q < 2; q++) {
+      const u32 bb = tid + 256u * q;                 // butterfly 0..511
+      // bb -> (pair index p over positions, tw): with TW side-by-side tiles the low logTW bits select the tile
+      const u32 tw = bb & (TW - 1), p = bb >> logTW;                 // p in [0, 512 / TW): over (chunk, j-pairs)
+      const u32 j0 = ((p >> ls) << (ls + 1)) + (p & ((1u << ls) - 1));   // position (chunk bits included for lo == 0)
+      const u32 e0 = (j0 << logTW) + tw, e1 = e0 + ((1u << ls) << logTW);
+      // r = global index of e0 mod 2^logm
+      const u32 r = lo == 0 ? (j0 & ((1u << ls) - 1)) : (((j0 & ((1u << ls) - 1)) << lo) + Lfull0 + tw);
+      fe w; twiddle(w, W, 1u << log_half_max, r << (log_half_max - logm), INV);
+      fe u, v, x, y;
+#pragma unroll
+      for (int l = 0; l < 8; l++) { u.v[l] = sm[l][e0]; v.v[l] = sm[l][e1]; }
+      if (!INV) { F::add(x, u, v); F::sub(y, u, v); F::mul(y, y, w); }
+      else { F::mul(v, v, w); F::add(x, u, v); F::sub(y, u, v); }
+#pragma unroll
+      for (int l = 0; l < 8; l++) { sm[l][e0] = x.v[l]; sm[l][e1] = y.v[l]; }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 e = tid + 256u * q;
+    const u64 g = gidx(e);
+    if (g < total) {
+      fe v;
+#pragma unroll
+      for (int l = 0; l < 8; l++) v.v[l] = sm[l][e];
+      st(buf + g * 8, v);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // one level: load (zero-padded children into the transform buffer), pointwise, store
 // buffer layout: seq (q * nnodes + k), q = 0: L.a, 1: L.b, 2: R.a, 3: R.b; results overwrite q = 0 (a) and 1 (b)

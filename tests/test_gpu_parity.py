@@ -967,6 +967,27 @@ def _sqrt_mod(a, p):
     return r
 
 
+@pytest.mark.parametrize("logn", [10, 11, 14, 18, 19, 21])
+def test_gpu_ntt_tiled_equals_stagewise(ctx, logn):
+    """the LDS-tiled passes (up to 10 stages per launch, strided tiles above 2^10) give bit for bit what one launch per stage
+    gives, forward and inverse, at every pass structure (1, 2 and 3 passes, short last groups)"""
+    p = pyref.GRUMPKIN.fp
+    rng = np.random.Generator(np.random.PCG64(1350 + logn))
+    nseq = 2 if logn <= 19 else 1
+    data = rng.integers(0, 1 << 62, size=(nseq << logn, 4), dtype=np.uint64)     # < 2^254: valid (if unusual) Montgomery limbs
+    data[:, 3] &= np.uint64((1 << 60) - 1)
+    outs = {}
+    for mode in (0, 2):
+        ctx.set_option("ntt_tiled", mode)
+        try:
+            f = ctx.debug_ntt(data, logn, False)
+            outs[mode] = (f, ctx.debug_ntt(f, logn, True))
+        finally:
+            ctx.set_option("ntt_tiled", 0)
+    assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1])
+    assert np.array_equal(outs[0][1], data)
+
+
 @pytest.mark.parametrize("logn", [1, 2, 5, 9, 12])
 def test_gpu_ntt_is_the_reference_fft(ctx, logn):
     """the device transform over bn256::Fr equals best_fft with the reference's own twiddle omega_pow(S - logn)
