@@ -335,10 +335,28 @@ class Context:
                                                    _ptr(a), cap, ctypes.byref(la), _ptr(b), cap, ctypes.byref(lb), _ptr(outp)))
         return a[: la.value].copy(), b[: lb.value].copy(), outp
 
-    def divisor_last_ntt(self) -> Tuple[float, int]:
-        ms = ctypes.c_double(); by = ctypes.c_uint64()
-        self._check(self.lib.lemsm_divisor_last_ntt(self.h, ctypes.byref(ms), ctypes.byref(by)))
-        return ms.value, by.value
+    def divisor_witness_batch(self, curve, lists, require_zero_sum: bool = True, normalise: bool = True):
+        """several point lists in one batch (lemsm_divisor_witness_batch); returns [(a, b, out_point)] per list"""
+        arrs = [_limbs(l, 8) if len(l) else np.zeros((0, 8), np.uint64) for l in lists]
+        T = len(arrs)
+        counts = np.array([a.shape[0] for a in arrs], np.uintp)
+        pts = np.concatenate(arrs) if T and counts.sum() else np.zeros((0, 8), np.uint64)
+        cap = int(counts.sum()) + 4 * T + 4
+        coeffs = np.zeros((cap, 4), np.uint64); index = np.zeros((max(T, 1), 4), np.uintp); outp = np.zeros((max(T, 1), 8), np.uint64)
+        szp = ctypes.POINTER(ctypes.c_size_t)
+        self._check(self.lib.lemsm_divisor_witness_batch(self.h, _curve_id(curve), _ptr(pts) if pts.size else None, counts.ctypes.data_as(szp), T,
+                                                         int(require_zero_sum), int(normalise), _ptr(coeffs), cap, index.ctypes.data_as(szp), _ptr(outp)))
+        out = []
+        for t in range(T):
+            oa, la, ob, lb = (int(v) for v in index[t])
+            out.append((coeffs[oa: oa + la].copy(), coeffs[ob: ob + lb].copy(), outp[t].copy()))
+        return out
+
+    def divisor_last_ntt(self) -> Tuple[float, int, int]:
+        """(device ms, algorithmic bytes, butterflies) of the transforms of the last divisor-witness call"""
+        ms = ctypes.c_double(); by = ctypes.c_uint64(); bf = ctypes.c_uint64()
+        self._check(self.lib.lemsm_divisor_last_ntt(self.h, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(bf)))
+        return ms.value, by.value, bf.value
 
     def lhs_witness(self, curve, scalars, pts_jacobian, base: int, normalise: bool = True):
         """compute_lhs_witness in full (src/argument_witness_calc.rs:87-136): (carry, [(a, b)] * d) with the functions in the

@@ -329,7 +329,6 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
                                                   const u32* __restrict__ W, u32 log_half_max) {
   __shared__ u32 sm[8][1024];
   const u32 tid = threadIdx.x;
-  const u32 J = 1u << S;
   const u32 TW = lo ? (1024u >> S) : 1u;            // lo > 0: TW tiles side by side; lo == 0: chunks of J inside 1024 contiguous
   const u32 logTW = lo ? (10u - S) : 0u;
   // element e of the tile -> global index

@@ -96,7 +96,7 @@ struct lemsm_ctx {
   DevBuf gather;    // multi-GPU: all ranks' raw per-window records after the all-gather
   DevBuf dw_tab, dw_arena, dw_tmp;   // divisor witness: twiddle / coset tables, level workspace, tmp point list
   u32 dw_logn = 0, dw_gexp = 0;      // tables hold transforms up to 2^dw_logn with coset generator 7^dw_gexp
-  double dw_ntt_ms = 0; u64 dw_ntt_bytes = 0;
+  double dw_ntt_ms = 0; u64 dw_ntt_bytes = 0, dw_ntt_bflies = 0;
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;

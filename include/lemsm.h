@@ -254,9 +254,17 @@ int lemsm_divisor_witness(lemsm_ctx* ctx, int curve, const uint64_t* points_affi
 int lemsm_divisor_witness_device(lemsm_ctx* ctx, int curve, const void* d_points_affine, size_t n, int require_zero_sum,
                                  int normalise, uint64_t* out_a, size_t cap_a, size_t* len_a, uint64_t* out_b,
                                  size_t cap_b, size_t* len_b, uint64_t out_point_affine[8]);
-/* Device time (ms) and algorithmic bytes (2 x 32 B read + 2 x 32 B written per butterfly and stage) of the transform
-   stages of the last divisor-witness call: the figures its HBM roofline is priced with. */
-int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithmic_bytes);
+/* T independent point lists in ONE batch (the merge trees of all lists advance level by level together: the launch
+   count of a single tree).  list t = counts[t] affine points, lists concatenated.  out_index: T x 4 entries
+   {offset_a, len_a, offset_b, len_b} in elements of 4 limbs into out_coeffs (sum(counts) + 4 T elements always suffice);
+   out_points_affine (optional): T x 8 limbs.  With require_zero_sum the first offending list is in lemsm_last_bad_index. */
+int lemsm_divisor_witness_batch(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, const size_t* counts, size_t T,
+                                int require_zero_sum, int normalise, uint64_t* out_coeffs, size_t cap_coeffs,
+                                size_t* out_index, uint64_t* out_points_affine);
+/* Device time (ms) of the transform launches of the last divisor-witness call, their algorithmic bytes (every element
+   read once and written once per pass over HBM: 1 pass up to 2^10 elements, 2 up to 2^18, 3 beyond) and their butterfly
+   count (one field multiplication each): the figures the HBM and VALU rooflines of the transforms are priced with. */
+int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithmic_bytes, uint64_t* butterflies);
 /* compute_lhs_witness in full (src/argument_witness_calc.rs:87-136): carry = sum_j scalars[j] pts[j] AND the d divisor
    witnesses of :129 (function f = digit iteration d - 1 - f, the reference's `ret.reverse()` order).
    out_coeffs: cap_coeffs field elements (4 limbs each); out_index: d x 4 entries {offset_a, len_a, offset_b, len_b} in

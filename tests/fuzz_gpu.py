@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from halo2_liam_eagen_msm_amd import api   # noqa: E402
 from oracle import cref, pyref             # noqa: E402
+from oracle import divisor as dv           # noqa: E402
+import json                                # noqa: E402
 
 CURVES = [pyref.BN254_G1, pyref.GRUMPKIN]
 
@@ -56,12 +58,92 @@ def make_case(rng, curve):
     return n, shape, sc, pts
 
 
+def _from_mont(arr, p):
+    rinv = pow(1 << 256, -1, p)
+    a = np.ascontiguousarray(arr, np.uint64).reshape(-1, 4)
+    return [int.from_bytes(a[i].tobytes(), "little") * rinv % p for i in range(a.shape[0])]
+
+
+def witness_case(rng, ctx, O, seed, cases):
+    """a forest of random point lists (identities, repeated points, P / -P neighbours) through lemsm_divisor_witness_batch
+    against the restatement of regular_functions_utils.rs: lengths exactly, coefficients normalised, outputs as points;
+    lists the reference panics on (two empty polynomials meeting) must be reported as such"""
+    g = pyref.GRUMPKIN; p = g.fp
+    pool = [g.raw_to_affine(r.tobytes()) for r in cref.gen_points(g.cid, int(rng.integers(1, 1 << 30)), 12)]
+    lists = []
+    for _ in range(int(rng.integers(1, 6))):
+        n = int(rng.choice([0, 1, 2, 3, 5, 8, 17, 40, 130]))
+        l = []
+        for _ in range(n):
+            r = rng.random()
+            if r < 0.12: l.append(None)
+            elif r < 0.25 and l and l[-1] is not None: l.append(g.neg(l[-1]))
+            elif r < 0.35 and l: l.append(l[-1])
+            else: l.append(pool[int(rng.integers(0, len(pool)))])
+        lists.append(l)
+    exp = []
+    panics = False
+    for l in lists:
+        try:
+            w, out = O.compute_divisor_witness_partial([O.from_affine(q) for q in l])
+            exp.append((O.normalise(w), O.to_affine(out)))
+        except pyref.RefPanic:
+            panics = True
+    rows = [np.frombuffer(b"".join(g.affine_to_raw(q) for q in l), np.uint64).reshape(-1, 8) if l else np.zeros((0, 8), np.uint64) for l in lists]
+    if panics:
+        try:
+            ctx.divisor_witness_batch(api.GRUMPKIN, rows, False, True)
+        except api.RefArithmeticOverflow:
+            return "witness(panic)"
+        print("MISMATCH seed=%d case=%d witness: the reference panics, the library did not" % (seed, cases), flush=True); sys.exit(1)
+    res = ctx.divisor_witness_batch(api.GRUMPKIN, rows, False, True)
+    for t, ((a, b, outp), (w, out)) in enumerate(zip(res, exp)):
+        if (_from_mont(a, p), _from_mont(b, p)) != w or g.raw_to_affine(outp.tobytes()) != out:
+            print("MISMATCH seed=%d case=%d witness list %d of lengths %s" % (seed, cases, t, [len(l) for l in lists]), flush=True); sys.exit(1)
+    return "witness"
+
+
+def scalar_witness_case(rng, ctx, seed, cases):
+    base = int(rng.choice([3, 5, 16, 17, 255])); nd = int(rng.integers(1, 60)); lt = int(rng.integers(1, 20))
+    vals = [int(rng.integers(0, 1 << 62)) << int(rng.integers(0, 66)) for _ in range(40)]
+    vals = [v if rng.random() < 0.7 else -v for v in vals]
+    sc = np.frombuffer(b"".join(abs(v).to_bytes(32, "little") for v in vals), np.uint8).reshape(-1, 32)
+    neg = np.array([1 if v < 0 else 0 for v in vals], np.uint8)
+    first = None; kinds = []
+    for j, v in enumerate(vals):
+        try:
+            kinds.append(pyref.prepare_scalar_witness(v, base, nd, lt))
+        except pyref.RefPanic as e:
+            kinds.append(e.kind)
+            if first is None: first = j
+    exc = {"too_many_digits": api.TooManyDigits, "index": api.RefIndexOutOfBounds, "overflow": api.RefArithmeticOverflow}
+    try:
+        arr = ctx.prepare_scalar_witness_batch(sc, neg, base, nd, lt)
+        if first is not None:
+            print("MISMATCH seed=%d case=%d scalar witness: expected %s at %d" % (seed, cases, kinds[first], first), flush=True); sys.exit(1)
+    except (api.TooManyDigits, api.RefIndexOutOfBounds, api.RefArithmeticOverflow) as e:
+        if first is None or not isinstance(e, exc[kinds[first]]) or e.index != first:
+            print("MISMATCH seed=%d case=%d scalar witness error %r, expected %s at %s" % (seed, cases, e, None if first is None else kinds[first], first), flush=True); sys.exit(1)
+        return "scalar_witness(panic)"
+    for j, v in enumerate(vals):
+        for r in range(base):
+            for c in range(arr.shape[2]):
+                e = arr[j, r, c]; val = (int(e["hi"]) << 64) | int(e["lo"]); want = kinds[j][r][c]
+                ok = api.ENTRY_KINDS[int(e["kind"])] == want[0] and (want[0] == "Scalar" or (val == want[1] and (want[0] == "Bucket" or int(e["mask"]) == want[2])))
+                if not ok:
+                    print("MISMATCH seed=%d case=%d scalar witness value base=%d nd=%d lt=%d v=%d cell %d,%d" % (seed, cases, base, nd, lt, v, r, c), flush=True); sys.exit(1)
+    return "scalar_witness"
+
+
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
     rng = np.random.default_rng(seed)
     ctx = api.Context(0)
-    t0 = time.time(); cases = 0
+    chains = json.load(open(os.path.join(ROOT, "tests", "golden", "fr_mont_chains.json")))
+    head = int.from_bytes(bytes.fromhex(chains["omega_pow"]["head"]), "little")
+    O = dv.DivisorOracle(pyref.GRUMPKIN, dv.FrFft(pyref.GRUMPKIN.fp, head * pow(1 << 256, -1, pyref.GRUMPKIN.fp) % pyref.GRUMPKIN.fp))
+    t0 = time.time(); cases = 0; kinds_seen = {}
     names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "seg_records", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows"]
     while time.time() - t0 < secs:
         curve = CURVES[int(rng.integers(0, 2))]
@@ -75,13 +157,22 @@ def main():
             opts["groups"] = int(rng.choice([0, 0, 2, 3]))     # pipelined window groups: device-pointer entries only
         for k in names:
             ctx.set_option(k, opts[k])
+        pick = rng.random()
+        if pick < 0.12:
+            k = witness_case(rng, ctx, O, seed, cases); kinds_seen[k] = kinds_seen.get(k, 0) + 1; cases += 1
+            continue
+        if pick < 0.18:
+            k = scalar_witness_case(rng, ctx, seed, cases); kinds_seen[k] = kinds_seen.get(k, 0) + 1; cases += 1
+            continue
+        sharded = (not host_entry) and opts["groups"] == 0 and rng.random() < 0.2      # the C ABI's multi-GPU entries, ranks simulated on this GPU
+        world = int(rng.choice([2, 3, 5, 8])) if sharded else 1
         if rng.random() < 0.75:
             n, shape, sc, pts = make_case(rng, curve)
             try:
                 got = ctx.msm(curve.cid, sc, pts) if host_entry else None
                 if got is None:
                     ds, dp = ctx.to_device(sc), ctx.to_device(pts)
-                    got = ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+                    got = ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, world) if sharded else ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
             except Exception as ex:
                 print("EXCEPTION %r seed=%d case=%d %s n=%d shape=%s host_entry=%s opts=%s" % (ex, seed, cases, curve.name, n, shape, host_entry, opts), flush=True)
                 raise
@@ -94,7 +185,11 @@ def main():
             if rng.random() < 0.3:
                 sc[:] = sc[0]
             pj = cref.aff_to_jac(curve.cid, pts)
-            got, carries = ctx.lhs_msm(curve.cid, sc, pj, base, True)
+            if sharded:
+                ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+                got, carries = ctx.debug_lhs_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, base, world)
+            else:
+                got, carries = ctx.lhs_msm(curve.cid, sc, pj, base, True)
             exp, ecar = cref.lhs_msm(curve.cid, sc, pj, base, True)
             for i in range(carries.shape[0]):
                 assert cref.jac_to_canonical(curve.cid, carries[i]) == cref.jac_to_canonical(curve.cid, ecar[i]), ("carry", i, seed, cases, opts)
@@ -106,7 +201,7 @@ def main():
         cases += 1
         if cases % 50 == 0:
             print("%d cases ok (%.0f s)" % (cases, time.time() - t0), flush=True)
-    print("fuzz ok: %d cases, seed %d" % (cases, seed))
+    print("fuzz ok: %d cases, seed %d, of which %s" % (cases, seed, kinds_seen))
 
 
 if __name__ == "__main__":

@@ -1187,3 +1187,24 @@ def test_validate_points_option(ctx):
     finally:
         ctx.set_option("validate_points", 0)
     ctx.msm(curve.cid, sc, bad2)      # unchecked: no error (the point is skipped)
+
+
+def test_divisor_witness_batch_is_a_forest(ctx):
+    """lemsm_divisor_witness_batch: lists of very different lengths (0, 1, 2, 5, 64, 333 points; one of them not summing
+    to zero, asked for as _partial) advance together level by level and each equals its own single-list witness"""
+    g = pyref.GRUMPKIN; p = g.fp
+    O = dv.DivisorOracle(g, _fr_fft())
+    rng = pyref.SplitMix64(2200)
+    lists = []
+    for n in (0, 1, 2, 5, 64, 333, 7):
+        pts = pyref.gen_points(g, rng, n)
+        lists.append(pts)
+    res = ctx.divisor_witness_batch(api.GRUMPKIN, [_aff_rows(g, l) if l else np.zeros((0, 8), np.uint64) for l in lists], False, True)
+    assert len(res) == len(lists)
+    for l, (a, b, outp) in zip(lists, res):
+        w, out = O.compute_divisor_witness_partial([O.from_affine(q) for q in l])
+        w = O.normalise(w)
+        assert (_from_mont(a, p), _from_mont(b, p)) == w, len(l)
+        assert g.raw_to_affine(outp.tobytes()) == O.to_affine(out), len(l)
+    with pytest.raises(api.SumNotIdentity):
+        ctx.divisor_witness_batch(api.GRUMPKIN, [_aff_rows(g, lists[3])], True, True)

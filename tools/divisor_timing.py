@@ -25,9 +25,9 @@ for logn in logns:
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter(); run(); best = min(best, time.perf_counter() - t0)
-    ms, by = ctx.divisor_last_ntt()
-    print("divisor witness 2^%d points: %.2f ms wall (%.1f ns/point), lengths (%d, %d); NTT stages %.2f ms device, %.2f GB algorithmic -> %.0f GB/s (%.3f of 8 TB/s)"
-          % (logn, best * 1e3, best * 1e9 / n, la.value, lb.value, ms, by / 1e9, by / ms / 1e6 if ms else 0, by / ms / 1e6 / 8000 if ms else 0), flush=True)
+    ms, by, bf = ctx.divisor_last_ntt()
+    print("divisor witness 2^%d points: %.2f ms wall (%.1f ns/point), lengths (%d, %d); transforms %.2f ms device: %.2f GB algorithmic -> %.0f GB/s (%.3f of 8 TB/s), %.3g butterflies -> %.1f G/s"
+          % (logn, best * 1e3, best * 1e9 / n, la.value, lb.value, ms, by / 1e9, by / ms / 1e6 if ms else 0, by / ms / 1e6 / 8000 if ms else 0, bf, bf / ms / 1e6 if ms else 0), flush=True)
     dp.free()
 # compute_lhs_witness in full at 2^14 / 2^16 (host-pointer entry: Jacobian points in, d functions out)
 for logn in [x for x in logns if x <= 18][-2:]:
@@ -40,7 +40,7 @@ for logn in [x for x in logns if x <= 18][-2:]:
     for base in (16,):
         t0 = time.perf_counter(); carry, fns = ctx.lhs_witness(1, sc, jac, base, True); dt = time.perf_counter() - t0
         t0 = time.perf_counter(); carry, fns = ctx.lhs_witness(1, sc, jac, base, True); dt = min(dt, time.perf_counter() - t0)
-        ms, by = ctx.divisor_last_ntt()
-        print("compute_lhs_witness 2^%d points base %d: %.1f ms wall for the carry + %d divisor witnesses (%d coefficients); NTT stages %.1f ms, %.0f GB/s algorithmic"
-              % (logn, base, dt * 1e3, len(fns), sum(a.shape[0] + b.shape[0] for a, b in fns), ms, by / ms / 1e6 if ms else 0), flush=True)
+        ms, by, bf = ctx.divisor_last_ntt()
+        print("compute_lhs_witness 2^%d points base %d: %.1f ms wall for the carry + %d divisor witnesses (%d coefficients); transforms %.1f ms, %.0f GB/s algorithmic, %.1f G butterflies/s"
+              % (logn, base, dt * 1e3, len(fns), sum(a.shape[0] + b.shape[0] for a, b in fns), ms, by / ms / 1e6 if ms else 0, bf / ms / 1e6 if ms else 0), flush=True)
     dp.free()
