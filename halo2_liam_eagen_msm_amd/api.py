@@ -341,7 +341,7 @@ class Context:
         T = len(arrs)
         counts = np.array([a.shape[0] for a in arrs], np.uintp)
         pts = np.concatenate(arrs) if T and counts.sum() else np.zeros((0, 8), np.uint64)
-        cap = int(counts.sum()) + 4 * T + 4
+        cap = 2 * int(counts.sum()) + 4 * T + 4
         coeffs = np.zeros((cap, 4), np.uint64); index = np.zeros((max(T, 1), 4), np.uintp); outp = np.zeros((max(T, 1), 8), np.uint64)
         szp = ctypes.POINTER(ctypes.c_size_t)
         self._check(self.lib.lemsm_divisor_witness_batch(self.h, _curve_id(curve), _ptr(pts) if pts.size else None, counts.ctypes.data_as(szp), T,
@@ -370,7 +370,7 @@ class Context:
             raise BadBase(_lib.LEMSM_ERR_BAD_BASE, "base must be in 3..=255")
         n = s.shape[0]
         d = num_digits(cid, base)
-        cap = d * (n + base + 4)
+        cap = 2 * d * (n + base + 3)
         coeffs = np.zeros((cap, 4), np.uint64)
         index = np.zeros((d, 4), np.uintp)
         carry = np.zeros(12, np.uint64)

@@ -422,30 +422,43 @@ __device__ __forceinline__ void eval_point(fe& x, const u32* __restrict__ W, u32
   else { fe p; ld(p, W + ((size_t)(j - halfN) << (log_half_max + 1 - logN)) * 8); F::neg(x, p); }
 }
 
+// the evaluation domain of one level, once for all nodes: XS[2i] = x_i = g omega_N^rev(i), XS[2i+1] = x_i^3 + B
+__global__ __launch_bounds__(256) void k_domain(u32 logN, const u32* __restrict__ W, u32 log_half_max, const u32* __restrict__ consts, u32* __restrict__ XS) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << logN)) return;
+  fe cb, cg, x, t, s; ld(cb, consts); ld(cg, consts + 16);
+  eval_point(x, W, log_half_max, logN, i); F::mul(x, x, cg);            // the coset keeps x_i - c != 0
+  F::sqr(t, x); F::mul(t, t, x); F::add(s, t, cb);
+  st(XS + (size_t)i * 16, x); st(XS + (size_t)i * 16 + 8, s);
+}
+
+// Thread c of a node owns the slots i = c + k * stride (stride = threads per node): the lanes of a wave touch
+// consecutive elements in every trip, and the thread's own KB slots share one inversion (Montgomery's trick).
 template <int KB>
 __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
-                                                   const u32* __restrict__ W, u32 log_half_max, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
+                                                   const u32* __restrict__ XS, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
                                                    u32* __restrict__ stats) {
   const u32 N = 1u << logN;
-  const u32 chunks = (N + KB - 1) / KB;
+  const u32 stride = (N + KB - 1) / KB;               // threads per node
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (u64)nnodes * chunks) return;
-  const u32 k = (u32)(gid / chunks), ch = (u32)(gid - (u64)k * chunks);
+  if (gid >= (u64)nnodes * stride) return;
+  const u32 k = (u32)(gid / stride), c = (u32)(gid - (u64)k * stride);
   const Plan& pl = plan[k];
   if (pl.mode == MODE_PASS) return;
-  const u32 i0 = ch * KB, i1 = min(N, i0 + KB);
   const size_t per = (size_t)nnodes << logN;
   u32* sLa = buf + (((size_t)k << logN)) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
-  fe cb, ninv, cg; ld(cb, consts); ld(ninv, consts + 8); ld(cg, consts + 16);
+  fe ninv; ld(ninv, consts + 8);
   fe c0, c1, d0, lX, lZZ, rX, rZZ;
   const bool divide = pl.mode == MODE_DIVIDE;
-  if (divide) { ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0); ld(lX, pl.lX); ld(lZZ, pl.lZZ); ld(rX, pl.rX); ld(rZZ, pl.rZZ); }
-  // pass 1: numerators into the L.a / L.b slots, running product of the denominators into the R.a slot
+  if (divide) {
+    ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0); ld(lX, pl.lX); ld(lZZ, pl.lZZ); ld(rX, pl.rX); ld(rZZ, pl.rZZ);
+    F::mul(c0, c0, ninv); F::mul(c1, c1, ninv); F::mul(d0, d0, ninv);   // the numerator is linear in the line: 1/N of the inverse transform rides on it
+  }
+  // pass 1: numerators into the L.a / L.b slots, prefix products of the denominators into the R.a slot
   fe run; F::set_one(run);
-  for (u32 i = i0; i < i1; i++) {
-    fe x, x3, s, La, Lb, Ra, Rb, A, Bv, t, u;
-    eval_point(x, W, log_half_max, logN, i); F::mul(x, x, cg);          // x_i = g omega^rev(i): the coset keeps x_i - c != 0
-    F::sqr(t, x); F::mul(x3, t, x); F::add(s, x3, cb);                 // s = x^3 + B  (y^2)
+  for (u32 i = c; i < N; i += stride) {
+    fe x, s, La, Lb, Ra, Rb, A, Bv, t, u;
+    ld(x, XS + (size_t)i * 16); ld(s, XS + (size_t)i * 16 + 8);        // x_i, x_i^3 + B (= y^2)
     ld(La, sLa + (size_t)i * 8); ld(Lb, sLb + (size_t)i * 8); ld(Ra, sRa + (size_t)i * 8); ld(Rb, sRb + (size_t)i * 8);
     if (divide) {
       fe l, tA, tB;
@@ -462,14 +475,16 @@ __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const 
     } else {
       F::mul(A, La, Ra); F::mul(t, Lb, Rb); F::mul(t, t, s); F::add(A, A, t);
       F::mul(Bv, La, Rb); F::mul(t, Lb, Ra); F::add(Bv, Bv, t);
+      F::mul(A, A, ninv); F::mul(Bv, Bv, ninv);                          // 1/N of the inverse transform
     }
-    F::mul(A, A, ninv); F::mul(Bv, Bv, ninv);                            // 1/N of the inverse transform
     st(sLa + (size_t)i * 8, A); st(sLb + (size_t)i * 8, Bv);
   }
   if (!divide) return;
-  // pass 2: Montgomery's trick backwards
+  // pass 2: Montgomery's trick backwards over the same slots
   fe inv; inv_fast(inv, run);
-  for (u32 i = i1; i-- > i0;) {
+  const u32 cnt = (N - c + stride - 1) / stride;      // slots of this thread
+  for (u32 q = cnt; q-- > 0;) {
+    const u32 i = c + q * stride;
     fe pref, den, di, A, Bv;
     ld(pref, sRa + (size_t)i * 8); ld(den, sRb + (size_t)i * 8);
     F::mul(di, inv, pref); F::mul(inv, inv, den);

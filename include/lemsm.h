@@ -256,7 +256,8 @@ int lemsm_divisor_witness_device(lemsm_ctx* ctx, int curve, const void* d_points
                                  size_t cap_b, size_t* len_b, uint64_t out_point_affine[8]);
 /* T independent point lists in ONE batch (the merge trees of all lists advance level by level together: the launch
    count of a single tree).  list t = counts[t] affine points, lists concatenated.  out_index: T x 4 entries
-   {offset_a, len_a, offset_b, len_b} in elements of 4 limbs into out_coeffs (sum(counts) + 4 T elements always suffice);
+   {offset_a, len_a, offset_b, len_b} in elements of 4 limbs into out_coeffs (a list of n points gives n + 1 coefficients in
+   all unless identities or P / -P pairs make the reference carry zero padding: 2 sum(counts) + 4 T elements always suffice);
    out_points_affine (optional): T x 8 limbs.  With require_zero_sum the first offending list is in lemsm_last_bad_index. */
 int lemsm_divisor_witness_batch(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, const size_t* counts, size_t T,
                                 int require_zero_sum, int normalise, uint64_t* out_coeffs, size_t cap_coeffs,
@@ -268,7 +269,8 @@ int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithm
 /* compute_lhs_witness in full (src/argument_witness_calc.rs:87-136): carry = sum_j scalars[j] pts[j] AND the d divisor
    witnesses of :129 (function f = digit iteration d - 1 - f, the reference's `ret.reverse()` order).
    out_coeffs: cap_coeffs field elements (4 limbs each); out_index: d x 4 entries {offset_a, len_a, offset_b, len_b} in
-   elements; d * (n + base + 4) elements always suffice. */
+   elements; a function over a list of c points has c + 1 coefficients in all (up to 2 c + 2 when identities or
+   opposite points make the reference carry zero padding): 2 d (n + base + 3) elements always suffice. */
 int lemsm_lhs_witness(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* pts_jacobian, size_t n,
                       uint8_t base, uint64_t out_carry[12], uint64_t* out_coeffs, size_t cap_coeffs, size_t* out_index,
                       int normalise, size_t* bad_index);
