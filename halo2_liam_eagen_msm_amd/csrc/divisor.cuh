@@ -433,13 +433,12 @@ __global__ __launch_bounds__(256) void k_domain(u32 logN, const u32* __restrict_
 }
 
 // Thread c of a node owns the slots i = c + k * stride (stride = threads per node): the lanes of a wave touch
-// consecutive elements in every trip, and the thread's own KB slots share one inversion (Montgomery's trick).
-template <int KB>
-__global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
+// consecutive elements in every trip, and the thread's own N / stride slots share one inversion (Montgomery's trick;
+// the host picks the share: 64 slots when there are millions of elements, fewer when a level is short on threads).
+__global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
                                                    const u32* __restrict__ XS, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
                                                    u32* __restrict__ stats) {
   const u32 N = 1u << logN;
-  const u32 stride = (N + KB - 1) / KB;               // threads per node
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (u64)nnodes * stride) return;
   const u32 k = (u32)(gid / stride), c = (u32)(gid - (u64)k * stride);

@@ -100,7 +100,7 @@ struct lemsm_ctx {
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0;
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -321,13 +321,22 @@ struct GroupWs {
   u32* rec_key_a; char* rec_pt_a; u32* rec_key_b; char* rec_pt_b;
   size_t zero_begin, zero_bytes;   // contiguous region to memset(0) per group (offset from base)
   size_t total;
+  std::vector<size_t> guards;      // option ws_canary: offsets of the 256-byte guard behind every sub-buffer
 };
 
 const u32 L2_RECORDS = 8;     // records per thread at the first edge-record level
 
-GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t ntasks_total, size_t ptb) {
+const size_t WS_GUARD = 256;
+GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t ntasks_total, size_t ptb, bool guard = false) {
   GroupWs w; size_t off = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  // option ws_canary (debug / fuzz): every sub-buffer is followed by a guard that run_group fills with a pattern and
+  // checks when the group is done -- an overrun of ANY sub-buffer shows up, not only one past the group's end
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    if (guard) { size_t g = align_up(off + bytes, 16); w.guards.push_back(g); off = align_up(g + WS_GUARD, 256); }
+    else off = align_up(off + bytes, 256);
+    return o;
+  };
   u32 NBpad = pl.nbins << pl.LB;
   // zeroed region first: bin_total, bin_cursor, bucket_count, bucket_cursor, bucket sums
   size_t z0 = off;
@@ -480,9 +489,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   PyrTask* d_tasks = (PyrTask*)pit->second.buf.p;
   CopyTask* d_copy = (CopyTask*)((char*)pit->second.buf.p + align_up(ntasks_total * sizeof(PyrTask), 256));
   const size_t ptb = G::PT_BYTES;
-  GroupWs w = carve(ws_base, pl, ar, ntasks_total, ptb);
+  GroupWs w = carve(ws_base, pl, ar, ntasks_total, ptb, ctx->opt_ws_canary != 0);
 
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
+  for (size_t g : w.guards) HIPCHK(ctx, hipMemsetAsync(ws_base + g, 0xA5, WS_GUARD, st));
 
   typename Prov::Dec dec;
   { int rcp = prov.prepare(ctx, st, pl, w.dig16, w.signbm, w.block_counts, w.bin_total, w.err, dec); if (rcp) return rcp; }
@@ -586,14 +596,21 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(d_out, w.arena + (size_t)ar.out_off * ptb, (size_t)gw * (L + 1) * ptb, hipMemcpyDeviceToDevice, st));
+  if (!w.guards.empty()) {   // debug: drain and verify every guard before the workspace is reused
+    std::vector<unsigned char> host(w.guards.size() * WS_GUARD);
+    for (size_t i = 0; i < w.guards.size(); i++) HIPCHK(ctx, hipMemcpyAsync(host.data() + i * WS_GUARD, ws_base + w.guards[i], WS_GUARD, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(s_sort)); HIPCHK(ctx, hipStreamSynchronize(s_acc)); HIPCHK(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < host.size(); i++)
+      if (host[i] != 0xA5) return fail(ctx, LEMSM_ERR_HIP, "workspace guard " + std::to_string(i / WS_GUARD) + " overwritten at byte " + std::to_string(i % WS_GUARD) + " (option ws_canary)");
+  }
   return LEMSM_OK;
 }
 
-size_t group_ws_bytes(const GroupPlan& pl, u32 nbp, u32 L, size_t ptb) {
+size_t group_ws_bytes(const GroupPlan& pl, u32 nbp, u32 L, size_t ptb, bool guard) {
   u32 gw = pl.w1 - pl.w0;
   ArenaLayout ar = make_arena(pl.nbins << pl.LB, nbp, gw, L);
   size_t ntasks = (size_t)(L + 2) * (L + 2);
-  GroupWs w = carve(nullptr, pl, ar, ntasks, ptb);
+  GroupWs w = carve(nullptr, pl, ar, ntasks, ptb, guard);
   return w.total + 4096;
 }
 
@@ -703,8 +720,8 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
     u32 sn0 = (u32)std::min(SLAB, n), snl = (u32)(n - (nslabs - 1) * SLAB);
     for (u32 g0 = wb; g0 < we; g0 += gsz) {
       u32 g1 = std::min(we, g0 + gsz);
-      size_t bytes = group_ws_bytes(make_group_plan(ctx, sn0, c, nb, W, g0, g1, d), nbp, L, ptb);
-      if (snl != sn0) bytes = std::max(bytes, group_ws_bytes(make_group_plan(ctx, snl, c, nb, W, g0, g1, d), nbp, L, ptb));
+      size_t bytes = group_ws_bytes(make_group_plan(ctx, sn0, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0);
+      if (snl != sn0) bytes = std::max(bytes, group_ws_bytes(make_group_plan(ctx, snl, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0));
       groups.push_back({g0, g1, ws_total});
       ws_total += align_up(bytes + 8192, 256);     // (+ slack for the 16-entry rounding of the accumulate chunk, see make_group_plan)
     }
@@ -778,7 +795,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
       // the group's non-canonical-scalar flag (first 8 bytes of its workspace) survives the workspace reuse
       HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT, ws_base + gr.off, 8, hipMemcpyDeviceToDevice, s_tail));
       {
-        GroupWs gw_ = carve(ws_base + gr.off, pl, make_arena(pl.nbins << pl.LB, nbp, gr.g1 - gr.g0, L), 0, ptb);
+        GroupWs gw_ = carve(ws_base + gr.off, pl, make_arena(pl.nbins << pl.LB, nbp, gr.g1 - gr.g0, L), 0, ptb, ctx->opt_ws_canary != 0);
         HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT + 16, gw_.meta + META_CLOCK, 32, hipMemcpyDeviceToDevice, s_tail));
       }
     }
@@ -1380,6 +1397,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
   else if (!strcmp(name, "xcd_windows")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_xcd_windows = value; }
+  else if (!strcmp(name, "ws_canary")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_ws_canary = value; }
   else if (!strcmp(name, "ntt_tiled")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_ntt_tiled = value; }
   else if (!strcmp(name, "pyr_fuse")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_fuse = value; }
   else if (!strcmp(name, "validate_points")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_validate_points = value; }

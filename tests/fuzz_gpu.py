@@ -135,23 +135,26 @@ def scalar_witness_case(rng, ctx, seed, cases):
     return "scalar_witness"
 
 
-def main():
-    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+def main(secs=None, seed=None):
+    if secs is None:
+        secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    if seed is None:
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
     rng = np.random.default_rng(seed)
     ctx = api.Context(0)
     chains = json.load(open(os.path.join(ROOT, "tests", "golden", "fr_mont_chains.json")))
     head = int.from_bytes(bytes.fromhex(chains["omega_pow"]["head"]), "little")
     O = dv.DivisorOracle(pyref.GRUMPKIN, dv.FrFft(pyref.GRUMPKIN.fp, head * pow(1 << 256, -1, pyref.GRUMPKIN.fp) % pyref.GRUMPKIN.fp))
     t0 = time.time(); cases = 0; kinds_seen = {}
-    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "seg_records", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows"]
+    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "seg_records", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows", "ws_canary", "pyr_fuse"]
     while time.time() - t0 < secs:
         curve = CURVES[int(rng.integers(0, 2))]
         opts = {"window_bits": int(rng.choice([0, 0, 2, 3, 5, 8, 11, 13, 16, 17])), "chunk": int(rng.choice([0, 0, 1, 3, 17, 64, 300])),
                 "tile": int(rng.choice([0, 0, 256, 1000])), "field": int(rng.choice([0, 0, 1])), "abi_points": int(rng.integers(0, 3)),
                 "slab_bits": int(rng.choice([0, 0, 12, 14])), "seg_records": int(rng.choice([0, 2, 5, 8, 16])),
                 "accum_waves": int(rng.choice([0, 0, 2, 4])), "host_slab_bits": int(rng.choice([0, 12, 13, 16])),
-                "groups": 0, "entry_ring": int(rng.integers(0, 2)), "xcd_windows": int(rng.integers(0, 2))}
+                "groups": 0, "entry_ring": int(rng.integers(0, 2)), "xcd_windows": int(rng.integers(0, 2)),
+                "ws_canary": int(rng.random() < 0.3), "pyr_fuse": int(rng.random() < 0.3)}
         host_entry = rng.random() < 0.5
         if not host_entry:
             opts["groups"] = int(rng.choice([0, 0, 2, 3]))     # pipelined window groups: device-pointer entries only
@@ -201,7 +204,11 @@ def main():
         cases += 1
         if cases % 50 == 0:
             print("%d cases ok (%.0f s)" % (cases, time.time() - t0), flush=True)
+    for k in names:
+        ctx.set_option(k, 0)
+    ctx.close()
     print("fuzz ok: %d cases, seed %d, of which %s" % (cases, seed, kinds_seen))
+    return cases
 
 
 if __name__ == "__main__":
