@@ -358,6 +358,12 @@ class Context:
         self._check(self.lib.lemsm_divisor_last_ntt(self.h, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(bf)))
         return ms.value, by.value, bf.value
 
+    def lhs_witness_last_phases(self) -> Tuple[float, float, float, float]:
+        """host-clock ms of the last lhs_witness call: (MSM core, point lists, merge forest, coefficient download)"""
+        out = (ctypes.c_double * 4)()
+        self._check(self.lib.lemsm_lhs_witness_last_phases(self.h, out))
+        return tuple(out)
+
     def lhs_witness(self, curve, scalars, pts_jacobian, base: int, normalise: bool = True):
         """compute_lhs_witness in full (src/argument_witness_calc.rs:87-136): (carry, [(a, b)] * d) with the functions in the
         reference's (reversed) order."""

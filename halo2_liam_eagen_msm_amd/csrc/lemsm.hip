@@ -18,6 +18,7 @@
 #include "rccl_dyn.hpp"
 #include "divisor.cuh"
 #include <rocprim/rocprim.hpp>
+#include <chrono>
 #include <functional>
 #include <thread>
 
@@ -97,6 +98,7 @@ struct lemsm_ctx {
   DevBuf dw_tab, dw_arena, dw_tmp;   // divisor witness: twiddle / coset tables, level workspace, tmp point list
   u32 dw_logn = 0, dw_gexp = 0;      // tables hold transforms up to 2^dw_logn with coset generator 7^dw_gexp
   double dw_ntt_ms = 0; u64 dw_ntt_bytes = 0, dw_ntt_bflies = 0;
+  double dw_phase_ms[4] = {0, 0, 0, 0};   // lhs witness: MSM core, point lists, merge forest, coefficient download
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;

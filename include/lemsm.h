@@ -276,6 +276,11 @@ int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithm
 int lemsm_lhs_witness(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* pts_jacobian, size_t n,
                       uint8_t base, uint64_t out_carry[12], uint64_t* out_coeffs, size_t cap_coeffs, size_t* out_index,
                       int normalise, size_t* bad_index);
+/* Host-clock milliseconds of the four phases of the last lemsm_lhs_witness call (each ends on a stream synchronise):
+   [0] the MSM core (upload of scalars and points, digits, buckets, carries), [1] the table of multiples and the d point
+   lists, [2] the merge forest (every field operation of the divisor witnesses), [3] the download of the coefficients
+   into the caller's buffer (32 B each over PCIe; pageable memory is paged in by this copy). */
+int lemsm_lhs_witness_last_phases(const lemsm_ctx* ctx, double out_ms[4]);
 
 /* ---- challenge post-processing helpers (src/config.rs:166-187) ------------------------ */
 /* Host-side (a handful of field operations each); field elements are raw Montgomery limbs of the BASE field of `curve`.

@@ -17,4 +17,4 @@ aff = dp.download(np.uint64).reshape(-1, 8)
 jac = np.zeros((n, 12), np.uint64); jac[:, :8] = aff; jac[:, 8:] = np.frombuffer(((1 << 256) % r).to_bytes(32, "little"), np.uint64)
 for _ in range(2):
     t0 = time.perf_counter(); carry, fns = ctx.lhs_witness(1, sc, jac, 16, True); dt = time.perf_counter() - t0
-print("2^%d: %.1f ms, %d functions, %d coefficients, ntt %s" % (logn, dt * 1e3, len(fns), sum(a.shape[0] + b.shape[0] for a, b in fns), ctx.divisor_last_ntt()))
+print("2^%d: %.1f ms, %d functions, %d coefficients, ntt %s" % (logn, dt * 1e3, len(fns), sum(a.shape[0] + b.shape[0] for a, b in fns), ctx.divisor_last_ntt()), "phases ms (msm, lists, forest, download)", ["%.1f" % v for v in ctx.lhs_witness_last_phases()])
