@@ -86,6 +86,8 @@ def main():
                          "ncclAllGather of raw device records) or the host-side torch.distributed all-gather of halo2_liam_eagen_msm_amd.dist")
     ap.add_argument("--sharding", choices=["windows", "points"], default="windows",
                     help="N > 1 partition of the MSM: Pippenger windows (north star, default) or pairs (SURVEY 8e alternative)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="lemsm_set_option tuning knob for A/B runs (repeatable); reported in config.options")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -141,6 +143,10 @@ def main():
             # 16 windows split evenly over 2/4/8 ranks; the single-GPU default at 2^24 (15 windows of 17 bits) does not
             # (the C ABI's sharded entry pins this itself)
             ctx.set_option("window_bits", 16)
+
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        ctx.set_option(name, int(val))
 
     def step():
         if args.workload == "msm":
@@ -239,6 +245,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ctx, cid, curve, scalars, d_points, n, logn, args, world)
             checks.append("sample vs oracle")
         # bit_exact is derived from checks that ran in THIS process (each raises on a mismatch); null when none did
+        if args.option:
+            out["config"]["options"] = args.option
         out["config"]["bit_exact"] = True if checks else None
         out["config"]["bit_exact_checks"] = checks
         print(json.dumps(out), flush=True)

@@ -377,7 +377,7 @@ class Context:
         n = s.shape[0]
         d = num_digits(cid, base)
         cap = 2 * d * (n + base + 3)
-        coeffs = np.zeros((cap, 4), np.uint64)
+        coeffs = np.empty((cap, 4), np.uint64)     # untouched pages cost nothing; the functions below are views into it
         index = np.zeros((d, 4), np.uintp)
         carry = np.zeros(12, np.uint64)
         bad = ctypes.c_size_t(0)
@@ -387,7 +387,7 @@ class Context:
         fns = []
         for f in range(d):
             oa, la, ob, lb = (int(v) for v in index[f])
-            fns.append((coeffs[oa: oa + la].copy(), coeffs[ob: ob + lb].copy()))
+            fns.append((coeffs[oa: oa + la], coeffs[ob: ob + lb]))
         return carry, fns
 
     def debug_ntt(self, data, logn: int, inverse: bool = False) -> np.ndarray:

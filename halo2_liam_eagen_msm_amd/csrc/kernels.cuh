@@ -244,7 +244,7 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
   for (int k = 0; k < PB; k++) {
     u32 b = t * PB + k;
     cnt[k] = b < pl.nbins ? bin_total[b] : 0;
-    tl[k] = (cnt[k] + pl.T2 - 1) / pl.T2;
+    tl[k] = (pl.bin_cap && cnt[k] <= pl.bin_cap) ? 0u : (cnt[k] + pl.T2 - 1) / pl.T2;   // tiles only for the bins k_binsort leaves alone
     s += cnt[k]; st += tl[k];
   }
   u32 tot, tott;
@@ -262,15 +262,18 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
   }
 }
 
-template <class Dec, int STG /* entries staged per block: STAGE, or 2*STAGE at 512 bins per window (keeps the runs 64 bytes) */>
-__global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
-                                                  const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
-                                                  u32* __restrict__ entries, u32 xcd_windows /* 1-D grid, one XCD per window */) {
+template <class Dec, int STG /* entries staged per block: STAGE, 2*STAGE, or 4*STAGE with 1024 threads (128-byte runs at 512 bins per window) */,
+          int BS = 256>
+__global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
+                                                 const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
+                                                 u32* __restrict__ entries, u32 xcd_windows /* 1-D grid, one XCD per window */) {
+  static_assert(BS == 256 || BS == 1024, "block size");
+  static_assert(STG <= 16384, "jl field is 14 bits");
   __shared__ u32 lstart[BW_MAX + 1];
   __shared__ u32 delta[BW_MAX];        // global position of a bin's run minus its position in the staging buffer
   __shared__ u32 lcur[BW_MAX];
-  __shared__ u32 wsum[4];
-  __shared__ u32 stage[STG];           // jl:13 | local:7 | sign:1 | bin:9  (jl = index inside the block's range)
+  __shared__ u32 wsum[16];
+  __shared__ u32 stage[STG];           // jl:14 | local:7 | sign:1 | bin:9  (jl = index inside the block's range)
   // Block -> (window, range).  With >= 8 windows (1-D grid of 8 * ceil(gw/8) * nblk1 blocks) all blocks of
   // one window carry the same blockIdx.x % 8, i.e. run on one XCD (guide T1: the label groups blocks by XCD):
   // neighbouring (block, bin) runs of a window are then written through ONE L2 and merge into whole lines --
@@ -286,43 +289,55 @@ __global__ __launch_bounds__(256) void k_scatter1(Dec dec, GroupPlan pl, const u
   const u32 w = pl.w0 + wl;
   const u32 lmask = (1u << pl.LB) - 1u;
   u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
-  // Issue every load of the block up front -- the digit column (STG/256 per thread) and this
+  // Issue every load of the block up front -- the digit column (STG/BS per thread) and this
   // block's bin counts -- so that their latencies overlap each other and the claim atomics
   // (a rolled loop waits out one memory latency per entry: measured 3x slower).
-  constexpr int PER = STG / 256;
+  constexpr int PER = STG / BS;
   u32 bk[PER], sg[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    u32 j = j0 + tid + 256u * k;
+    u32 j = j0 + tid + (u32)BS * k;
     bk[k] = 0; sg[k] = 0;
     if (j < j1) dec.get(j, w, pl, bk[k], sg[k]);
   }
-  // up to BW_MAX = 512 bins per window: two bins per thread (tid and tid + 256)
   const size_t crow = ((size_t)wl * pl.nblk1 + r) * pl.BW;
-  u32 cnt0 = tid < pl.BW ? block_counts[crow + tid] : 0u;
-  u32 cnt1 = tid + 256u < pl.BW ? block_counts[crow + tid + 256u] : 0u;
-  u32 total0, total1;
-  u32 off0 = block_excl_scan_256(cnt0, &total0, wsum);
-  u32 off1 = block_excl_scan_256(cnt1, &total1, wsum) + total0;
-  const u32 total = total0 + total1;
-  lstart[tid] = off0; lstart[tid + 256u] = off1;
-  if (tid == 255) lstart[BW_MAX] = total;
-  delta[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) - off0 : 0u;
-  delta[tid + 256u] = cnt1 ? bin_start[wl * pl.BW + tid + 256u] + atomicAdd(&bin_cursor[wl * pl.BW + tid + 256u], cnt1) - off1 : 0u;
-  lcur[tid] = 0; lcur[tid + 256u] = 0;
+  u32 total;
+  if constexpr (BS == 256) {
+    // up to BW_MAX = 512 bins per window: two bins per thread (tid and tid + 256)
+    u32 cnt0 = tid < pl.BW ? block_counts[crow + tid] : 0u;
+    u32 cnt1 = tid + 256u < pl.BW ? block_counts[crow + tid + 256u] : 0u;
+    u32 total0, total1;
+    u32 off0 = block_excl_scan_256(cnt0, &total0, wsum);
+    u32 off1 = block_excl_scan_256(cnt1, &total1, wsum) + total0;
+    total = total0 + total1;
+    lstart[tid] = off0; lstart[tid + 256u] = off1;
+    if (tid == 255) lstart[BW_MAX] = total;
+    delta[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) - off0 : 0u;
+    delta[tid + 256u] = cnt1 ? bin_start[wl * pl.BW + tid + 256u] + atomicAdd(&bin_cursor[wl * pl.BW + tid + 256u], cnt1) - off1 : 0u;
+    lcur[tid] = 0; lcur[tid + 256u] = 0;
+  } else {
+    u32 cnt0 = tid < pl.BW ? block_counts[crow + tid] : 0u;
+    u32 off0 = block_excl_scan_1024(cnt0, &total, wsum);
+    if (tid < BW_MAX) {
+      lstart[tid] = off0;
+      delta[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) - off0 : 0u;
+      lcur[tid] = 0;
+    }
+    if (tid == 0) lstart[BW_MAX] = total;
+  }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     if (bk[k]) {
       u32 kk = bk[k] - 1u, b = kk >> pl.LB;
       u32 q = lstart[b] + atomicAdd(&lcur[b], 1u);
-      stage[q] = (tid + 256u * k) | ((kk & lmask) << 13) | (sg[k] << 20) | (b << 21);
+      stage[q] = (tid + (u32)BS * k) | ((kk & lmask) << 14) | (sg[k] << 21) | (b << 22);
     }
   }
   __syncthreads();
-  for (u32 q = tid; q < total; q += 256) {
+  for (u32 q = tid; q < total; q += BS) {
     u32 v = stage[q];
-    entries[delta[v >> 21] + q] = (j0 + (v & 0x1fffu)) | (((v >> 13) & 127u) << 24) | (((v >> 20) & 1u) << 31);
+    entries[delta[v >> 22] + q] = (j0 + (v & 0x3fffu)) | (((v >> 14) & 127u) << 24) | (((v >> 21) & 1u) << 31);
   }
 }
 
@@ -390,7 +405,9 @@ __global__ __launch_bounds__(256) void k_bucketscan(GroupPlan pl, const u32* __r
   __syncthreads();
   if (key < nkeys) {
     u32 first = tid & ~((1u << pl.LB) - 1u);          // first bucket of this thread's bin inside the block
-    bucket_start[key] = bin_start[key >> pl.LB] + (e - ex[first]);
+    const u32 b0 = bin_start[key >> pl.LB];
+    if (!(pl.bin_cap && bin_start[(key >> pl.LB) + 1] - b0 <= pl.bin_cap))   // (k_binsort wrote the starts of the bins it sorted)
+      bucket_start[key] = b0 + (e - ex[first]);
   }
   if (key == 0) bucket_start[nkeys] = bin_start[pl.nbins];
 }
@@ -439,6 +456,64 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
     u32 v = stage[q];
     sorted[delta[(v >> 24) & 127u] + q] = v & 0x80ffffffu;
   }
+}
+
+// pass 2 in one launch for every bin that fits LDS (the common case: 2^15 entries per bin at 2^24 points and 17-bit
+// windows): ONE 1024-thread block loads the whole bin into registers, ranks every entry inside its bucket with the LDS
+// histogram atomic, scans the 2^LB counts, stages the bin bucket-sorted in LDS and streams it out -- no count pass, no
+// global atomics, no tile table, and the bucket starts fall out of the block's own scan.  Bins over pl.bin_cap entries
+// (skewed scalars) are left to the tiled kernels above, whose tile table then lists those bins only.
+static const u32 BIN_CAP = 36864;    // 144 KiB of the CU's 160 KiB LDS
+__global__ __launch_bounds__(1024) void k_binsort(GroupPlan pl, const u32* __restrict__ entries, const u32* __restrict__ bin_start,
+                                                  u32* __restrict__ sorted, u32* __restrict__ bucket_start) {
+  __shared__ u32 stage[BIN_CAP];
+  __shared__ u32 hist[256];
+  __shared__ u32 lstart[256];
+  __shared__ u32 wsum[4];
+  const u32 tid = threadIdx.x, bin = blockIdx.x;
+  const u32 off = bin_start[bin], end = bin_start[bin + 1], cnt = end - off;
+  if (cnt > pl.bin_cap) return;
+  const u32 nl = 1u << pl.LB, lmask = nl - 1u;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  constexpr int PER = BIN_CAP / 1024;
+  u32 e[PER], rk[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) { u32 i = off + tid + 1024u * k; e[k] = i < end ? entries[i] : 0u; }
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    u32 i = off + tid + 1024u * k;
+    rk[k] = i < end ? atomicAdd(&hist[(e[k] >> 24) & lmask], 1u) : 0u;
+  }
+  __syncthreads();
+  if (tid < 256) {     // (whole waves: block_excl_scan_256 has barriers, so the other waves wait below)
+    u32 c = tid < nl ? hist[tid] : 0u, total;
+    // scan across the first four waves only: shuffles inside a wave, wave totals through LDS with a flag-free
+    // hand-off (the fifth barrier below orders it for everyone else)
+    const u32 lane = tid & 63, wave = tid >> 6;
+    u32 x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o); if (lane >= (u32)o) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    lstart[tid] = x - c;     // exclusive inside the wave; the wave base is added by the readers
+    (void)total;
+  }
+  __syncthreads();
+  const u32 wb1 = wsum[0], wb2 = wb1 + wsum[1], wb3 = wb2 + wsum[2];
+  if (tid < nl) {
+    u32 l = tid, base = l < 64 ? 0u : (l < 128 ? wb1 : (l < 192 ? wb2 : wb3));
+    bucket_start[(bin << pl.LB) + l] = off + base + lstart[l];
+  }
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    u32 i = off + tid + 1024u * k;
+    if (i < end) {
+      u32 l = (e[k] >> 24) & lmask, base = l < 64 ? 0u : (l < 128 ? wb1 : (l < 192 ? wb2 : wb3));
+      stage[base + lstart[l] + rk[k]] = e[k] & 0x80ffffffu;
+    }
+  }
+  __syncthreads();
+  for (u32 q = tid; q < cnt; q += 1024) sorted[off + q] = stage[q];
 }
 
 // copy single points (task results that are already final, e.g. U_{L-1} = A^{L-1}[1])

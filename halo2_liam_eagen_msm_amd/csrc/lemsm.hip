@@ -102,7 +102,7 @@ struct lemsm_ctx {
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0;
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -387,6 +387,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   spb = std::max(256u, std::min((u32)STAGE, spb));
   spb = (spb + 255) / 256 * 256;
   if (n >= (1u << 16)) spb = STAGE;     // long (block, bin) runs -> full-line writes
+  if (n >= (1u << 16) && d == 0 && ctx->opt_stage2x == 4) spb = 4 * STAGE;   // 1024-thread pass-1 blocks staging 16384 entries: 128-byte runs at 512 bins per window
   if (n >= (1u << 16) && d == 0 && ctx->opt_stage2x == 2) spb = 2 * STAGE;   // A/B knob: 64-byte runs at 512 bins per window; measured slower (fewer resident blocks), profiles/r01/y_scatter1_staging_ab.txt
   g.spb = spb;
   g.nblk1 = (n + spb - 1) / spb;
@@ -395,6 +396,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   u32 T2 = ctx->opt_tile > 0 ? std::min((u32)ctx->opt_tile, (u32)STAGE2) : (u32)STAGE2;
   g.T2 = T2;
   g.max_tiles = (u32)(Mmax / T2) + g.nbins + 1;
+  g.bin_cap = ctx->opt_binsort == 2 ? 0u : (ctx->opt_binsort > 2 ? std::min((u32)ctx->opt_binsort, (u32)BIN_CAP) : (u32)BIN_CAP);
   u32 L1;
   if (ctx->opt_chunk > 0) L1 = (u32)ctx->opt_chunk;
   else {
@@ -432,7 +434,10 @@ struct PipProvider {
     dec.dig16 = dig16; dec.signbm = nullptr;
     if (pl.c == 17) {
       dec.signbm = signbm;
-      hipLaunchKernelGGL((k_pip_digits<2>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+      if (pl.nblk1 < 2048)
+        hipLaunchKernelGGL((k_pip_digits<2, 1024>), dim3(pl.nblk1), dim3(1024), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
+      else
+        hipLaunchKernelGGL((k_pip_digits<2>), dim3(pl.nblk1), dim3(256), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
     } else if (pl.c == 16 && pl.W == 16) {
       if (pl.nblk1 < 1024)   // too few ranges to fill 256 CUs with 256-thread blocks
         hipLaunchKernelGGL((k_pip_digits<1, 1024>), dim3(pl.nblk1), dim3(1024), 0, st, scalars, kadd, pl, dig16, signbm, block_counts, bin_total, err);
@@ -502,7 +507,9 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   // >= 8 windows: 1-D grid, one XCD per window (see the kernel); else (windows, ranges)
   const u32 xw = (gw >= 8 && ctx->opt_xcd_windows != 1) ? 1u : 0u;
   dim3 g1 = xw ? dim3(8u * ((gw + 7) / 8) * pl.nblk1) : dim3(gw, pl.nblk1);
-  if (pl.spb > STAGE)
+  if (pl.spb > 2 * STAGE)
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 4 * STAGE, 1024>), g1, dim3(1024), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
+  else if (pl.spb > STAGE)
     hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 2 * STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
   else
     hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
@@ -511,6 +518,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   const u32* d_sorted = w.entries;
   const u32* d_bstart = w.bin_start;
   if (pl.LB > 0) {
+    if (pl.bin_cap) hipLaunchKernelGGL(k_binsort, dim3(pl.nbins), dim3(1024), 0, st, pl, w.entries, w.bin_start, w.sorted, w.bucket_start);
     hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
     hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
     hipLaunchKernelGGL(k_bucketscan, dim3(((pl.nbins << pl.LB) + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
@@ -1393,11 +1401,12 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   if (!ctx || !name) return LEMSM_ERR_BAD_ARG;
   if (!strcmp(name, "window_bits")) { if (value != 0 && (value < 2 || value > 17)) return LEMSM_ERR_BAD_ARG; ctx->opt_window_bits = value; }
   else if (!strcmp(name, "chunk")) { if (value < 0 || value > 65536) return LEMSM_ERR_BAD_ARG; ctx->opt_chunk = value; }
+  else if (!strcmp(name, "binsort")) { if (value < 0) return LEMSM_ERR_BAD_ARG; ctx->opt_binsort = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
   else if (!strcmp(name, "seg_records")) { if (value < 0 || value > 64 || value == 1) return LEMSM_ERR_BAD_ARG; ctx->opt_seg_records = value; }
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
-  else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
+  else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 4 || value == 3) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
   else if (!strcmp(name, "xcd_windows")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_xcd_windows = value; }
   else if (!strcmp(name, "ws_canary")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_ws_canary = value; }
   else if (!strcmp(name, "ntt_tiled")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_ntt_tiled = value; }

@@ -29,6 +29,7 @@ struct GroupPlan {
   uint32_t nblk1;    // pass-1 blocks = ceil(n / spb)
   uint32_t T2;       // entries per pass-2 tile
   uint32_t max_tiles;// upper bound on pass-2 tiles
+  uint32_t bin_cap;  // pass 2: bins of at most this many entries are sorted whole by ONE block (k_binsort); 0 = every bin goes through the tiled path
   uint32_t L1;       // entries per thread in the accumulate kernel
   uint32_t nthr1;    // upper bound on accumulate threads = ceil(n*(w1-w0) / L1)
   uint32_t d;        // negabase: digits per scalar (number of rows of the position-major digit matrix)

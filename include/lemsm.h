@@ -86,7 +86,9 @@ size_t lemsm_last_bad_index(const lemsm_ctx* ctx);
    means the digits no longer recompose the scalar. */
 size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
 /* Tuning / test knobs: "window_bits" (0 = auto), "chunk" (entries per accumulate thread,
-   0 = auto), "tile" (pass-2 tile entries, 0 = auto), "field" (0 = lazy radix-2^29 arithmetic, the default;
+   0 = auto), "tile" (pass-2 tile entries, 0 = auto), "binsort" (pass 2: 0/1 = bins of up to 36 864
+   entries are bucket-sorted whole by one block, larger ones by the tiled kernels; 2 = tiled kernels only (A/B knob);
+   > 2 = that capacity instead of 36 864, for tests that want both paths in one call), "field" (0 = lazy radix-2^29 arithmetic, the default;
    1 = strict 32-bit-limb arithmetic, kept for A/B and as an in-library cross-check),
    "accum_waves" (2..4 waves per SIMD of the accumulate kernel, 0 = auto), "groups" (window groups
    pipelined over three queues, device-pointer entries only; 0 = one group),
