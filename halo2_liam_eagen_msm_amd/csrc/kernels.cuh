@@ -87,7 +87,7 @@ __global__ __launch_bounds__(BS) void k_pip_digits(const uint4* __restrict__ sca
           u32 raw = extract_bits(s, 17u * w, 17u);
           u32 sign = ((u32)w + 1 < pl.W && raw < 65536u) ? 1u : 0u;
           u32 mag = ((u32)w + 1 < pl.W) ? (sign ? 65536u - raw : raw - 65536u) : raw;
-          dig16[(size_t)((u32)w - pl.w0) * pl.n + j] = (uint16_t)(sign ? mag - 1u : mag);
+          dig16[(size_t)((u32)w - pl.w0) * pl.dstride + j] = (uint16_t)(sign ? mag - 1u : mag);
           unsigned long long bal = __ballot(sign != 0);
           if ((threadIdx.x & 63u) == 0) signbm[(size_t)((u32)w - pl.w0) * ((pl.n + 63) / 64) + (j >> 6)] = bal;
           if (mag) atomicAdd(&hist[((u32)w - pl.w0) * pl.BW + ((mag - 1u) >> pl.LB)], 1u);
@@ -99,14 +99,14 @@ __global__ __launch_bounds__(BS) void k_pip_digits(const uint4* __restrict__ sca
         for (int w = 0; w < 16; w++) {
           if ((u32)w < pl.w0 || (u32)w >= pl.w1) continue;
           u32 raw = (w & 1) ? (s[w >> 1] >> 16) : (s[w >> 1] & 0xffffu);
-          dig16[(size_t)((u32)w - pl.w0) * pl.n + j] = (uint16_t)raw;
+          dig16[(size_t)((u32)w - pl.w0) * pl.dstride + j] = (uint16_t)raw;
           u32 bucket = ((u32)w + 1 < pl.W) ? (raw < half ? half - raw : raw - half) : raw;
           if (bucket) atomicAdd(&hist[((u32)w - pl.w0) * pl.BW + ((bucket - 1u) >> pl.LB)], 1u);
         }
       } else {
         for (u32 w = pl.w0; w < pl.w1; w++) {
           u32 raw = extract_bits(s, w * pl.c, pl.c);
-          dig16[(size_t)(w - pl.w0) * pl.n + j] = (uint16_t)raw;
+          dig16[(size_t)(w - pl.w0) * pl.dstride + j] = (uint16_t)raw;
           u32 bucket = (w + 1 < pl.W) ? (raw < half ? half - raw : raw - half) : raw;
           if (bucket) atomicAdd(&hist[(w - pl.w0) * pl.BW + ((bucket - 1u) >> pl.LB)], 1u);
         }
@@ -117,17 +117,21 @@ __global__ __launch_bounds__(BS) void k_pip_digits(const uint4* __restrict__ sca
   for (u32 i = tid; i < pl.nbins; i += BS) {
     u32 cnt = hist[i];
     u32 wl = i / pl.BW, bin = i - wl * pl.BW;
-    block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + bin] = cnt;
-    if (cnt) atomicAdd(&bin_total[i], cnt);
+    const size_t slot = ((size_t)wl * pl.nblk1 + r) * pl.BW + bin;
+    block_counts[slot] = cnt;
+    // the total's atomic is also the claim: what it returns is where this block's run starts inside the bin
+    // (pass 1 used to claim with a second round of atomics per (block, bin))
+    block_counts[(size_t)pl.nblk1 * pl.nbins + slot] = cnt ? atomicAdd(&bin_total[i], cnt) : 0u;
   }
 }
 
 // decoders: bucket (0 = skip) and sign of scalar j in window w
 struct PipDec {
+  static constexpr bool VEC = true;   // pass 1 reads 16 consecutive digits of a column with two 16-byte loads
   const uint16_t* dig16;
   const unsigned long long* signbm;   // c = 17 only (null otherwise)
   __device__ __forceinline__ void get(u32 j, u32 w, const GroupPlan& pl, u32& bucket, u32& sign) const {
-    u32 raw = dig16[(size_t)(w - pl.w0) * pl.n + j];
+    u32 raw = dig16[(size_t)(w - pl.w0) * pl.dstride + j];
     if (signbm) {                      // c = 17 encoding, see k_pip_digits<2>
       sign = (u32)(signbm[(size_t)(w - pl.w0) * ((pl.n + 63) / 64) + (j >> 6)] >> (j & 63u)) & 1u;
       bucket = sign ? raw + 1u : raw;
@@ -143,6 +147,7 @@ struct PipDec {
 // negabase digit matrix, position-major; bucket id = digit (id_by_digit: digit-1, 0 skipped;
 // src/negbase_utils.rs:46-51)
 struct NegDec {
+  static constexpr bool VEC = false;
   const uint8_t* digitsT;   // d x nstride, already offset to this slab's first column
   __device__ __forceinline__ void get(u32 j, u32 w, const GroupPlan& pl, u32& bucket, u32& sign) const {
     bucket = digitsT[(size_t)w * pl.nstride + j]; sign = 0;
@@ -205,8 +210,9 @@ __global__ __launch_bounds__(256) void k_count1(Dec dec, GroupPlan pl, u32* __re
   __syncthreads();
   if (tid < pl.BW) {
     u32 cnt = hist[tid];
-    block_counts[((size_t)wl * pl.nblk1 + r) * pl.BW + tid] = cnt;
-    if (cnt) atomicAdd(&bin_total[wl * pl.BW + tid], cnt);
+    const size_t slot = ((size_t)wl * pl.nblk1 + r) * pl.BW + tid;
+    block_counts[slot] = cnt;
+    block_counts[(size_t)pl.nblk1 * pl.nbins + slot] = cnt ? atomicAdd(&bin_total[wl * pl.BW + tid], cnt) : 0u;   // (the claim, as in k_pip_digits)
   }
 }
 
@@ -262,14 +268,12 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
   }
 }
 
-template <class Dec, int STG /* entries staged per block: STAGE, 2*STAGE, or 4*STAGE with 1024 threads (128-byte runs at 512 bins per window) */,
-          int BS = 256>
+template <class Dec, int STG /* entries staged per block: STAGE, 2*STAGE, or 4*STAGE with 1024 threads */, int BS = 256>
 __global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
-                                                 const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
+                                                 const u32* __restrict__ bin_start,
                                                  u32* __restrict__ entries, u32 xcd_windows /* 1-D grid, one XCD per window */) {
   static_assert(BS == 256 || BS == 1024, "block size");
   static_assert(STG <= 16384, "jl field is 14 bits");
-  __shared__ u32 lstart[BW_MAX + 1];
   __shared__ u32 delta[BW_MAX];        // global position of a bin's run minus its position in the staging buffer
   __shared__ u32 lcur[BW_MAX];
   __shared__ u32 wsum[16];
@@ -289,49 +293,82 @@ __global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u3
   const u32 w = pl.w0 + wl;
   const u32 lmask = (1u << pl.LB) - 1u;
   u32 j0 = r * pl.spb, j1 = min(j0 + pl.spb, pl.n);
-  // Issue every load of the block up front -- the digit column (STG/BS per thread) and this
-  // block's bin counts -- so that their latencies overlap each other and the claim atomics
-  // (a rolled loop waits out one memory latency per entry: measured 3x slower).
+  // Issue every load of the block up front -- the digits and this block's bin counts and claimed offsets -- so that
+  // their latencies overlap (a rolled loop waits out one memory latency per entry: measured 3x slower).
   constexpr int PER = STG / BS;
-  u32 bk[PER], sg[PER];
+  u32 bk[PER];   // bucket | sign << 31   (0 = no entry)
+  u32 jl0, jls;  // entry k of this thread is scalar j0 + jl0 + jls * k
+  if constexpr (Dec::VEC) {
+    // PER consecutive digits of the column per thread: PER/8 16-byte loads (columns are 16-byte aligned: pl.dstride)
+    // and the PER sign bits in one word, instead of 2 * PER scalar loads with their 64-bit address arithmetic
+    static_assert(PER == 16 || PER == 32, "digits per thread");
+    jl0 = tid * PER; jls = 1;
+    const u32 jb = j0 + jl0;
+    uint4 dv[PER / 8];
+    u32 sbits = 0;
+    if (jb < j1) {
+      const uint4* p = (const uint4*)(dec.dig16 + (size_t)wl * pl.dstride + jb);
 #pragma unroll
-  for (int k = 0; k < PER; k++) {
-    u32 j = j0 + tid + (u32)BS * k;
-    bk[k] = 0; sg[k] = 0;
-    if (j < j1) dec.get(j, w, pl, bk[k], sg[k]);
+      for (int v = 0; v < PER / 8; v++) dv[v] = p[v];
+      if (dec.signbm) {
+        const unsigned long long* sw = dec.signbm + (size_t)wl * ((pl.n + 63) / 64);
+        if (PER == 16) sbits = ((const uint16_t*)sw)[jb >> 4]; else sbits = ((const u32*)sw)[jb >> 5];
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < PER / 8; v++) dv[v] = make_uint4(0, 0, 0, 0);
+    }
+    const u32 half = 1u << (pl.c - 1);
+    const bool top = !(w + 1 < pl.W);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const uint4 q4 = dv[k / 8];
+      const u32 word = ((k / 2) % 4 == 0) ? q4.x : ((k / 2) % 4 == 1) ? q4.y : ((k / 2) % 4 == 2) ? q4.z : q4.w;
+      const u32 raw = (k & 1) ? (word >> 16) : (word & 0xffffu);
+      u32 bucket, sign;
+      if (dec.signbm) { sign = (sbits >> k) & 1u; bucket = raw + sign; }                       // c = 17 encoding, see k_pip_digits<2>
+      else if (top) { sign = 0; bucket = raw; }
+      else { sign = raw < half ? 1u : 0u; bucket = sign ? half - raw : raw - half; }
+      bk[k] = (jb + (u32)k < j1 && bucket) ? (bucket | (sign << 31)) : 0u;
+    }
+  } else {
+    jl0 = tid; jls = BS;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      u32 j = j0 + tid + (u32)BS * k, b = 0, sgn = 0;
+      if (j < j1) dec.get(j, w, pl, b, sgn);
+      bk[k] = b ? (b | (sgn << 31)) : 0u;
+    }
   }
   const size_t crow = ((size_t)wl * pl.nblk1 + r) * pl.BW;
+  const u32* __restrict__ block_offs = block_counts + (size_t)pl.nblk1 * pl.nbins;   // claimed by the counting kernel's atomics
   u32 total;
   if constexpr (BS == 256) {
     // up to BW_MAX = 512 bins per window: two bins per thread (tid and tid + 256)
-    u32 cnt0 = tid < pl.BW ? block_counts[crow + tid] : 0u;
-    u32 cnt1 = tid + 256u < pl.BW ? block_counts[crow + tid + 256u] : 0u;
+    const bool h0 = tid < pl.BW, h1 = tid + 256u < pl.BW;
+    u32 cnt0 = h0 ? block_counts[crow + tid] : 0u, cnt1 = h1 ? block_counts[crow + tid + 256u] : 0u;
+    u32 g0 = h0 ? bin_start[wl * pl.BW + tid] + block_offs[crow + tid] : 0u;
+    u32 g1 = h1 ? bin_start[wl * pl.BW + tid + 256u] + block_offs[crow + tid + 256u] : 0u;
     u32 total0, total1;
     u32 off0 = block_excl_scan_256(cnt0, &total0, wsum);
     u32 off1 = block_excl_scan_256(cnt1, &total1, wsum) + total0;
     total = total0 + total1;
-    lstart[tid] = off0; lstart[tid + 256u] = off1;
-    if (tid == 255) lstart[BW_MAX] = total;
-    delta[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) - off0 : 0u;
-    delta[tid + 256u] = cnt1 ? bin_start[wl * pl.BW + tid + 256u] + atomicAdd(&bin_cursor[wl * pl.BW + tid + 256u], cnt1) - off1 : 0u;
-    lcur[tid] = 0; lcur[tid + 256u] = 0;
+    delta[tid] = g0 - off0; delta[tid + 256u] = g1 - off1;
+    lcur[tid] = off0; lcur[tid + 256u] = off1;     // the cursor of a bin starts at its run: one LDS operation ranks and places an entry
   } else {
-    u32 cnt0 = tid < pl.BW ? block_counts[crow + tid] : 0u;
+    const bool h0 = tid < pl.BW;
+    u32 cnt0 = h0 ? block_counts[crow + tid] : 0u;
+    u32 g0 = h0 ? bin_start[wl * pl.BW + tid] + block_offs[crow + tid] : 0u;
     u32 off0 = block_excl_scan_1024(cnt0, &total, wsum);
-    if (tid < BW_MAX) {
-      lstart[tid] = off0;
-      delta[tid] = cnt0 ? bin_start[wl * pl.BW + tid] + atomicAdd(&bin_cursor[wl * pl.BW + tid], cnt0) - off0 : 0u;
-      lcur[tid] = 0;
-    }
-    if (tid == 0) lstart[BW_MAX] = total;
+    if (tid < BW_MAX) { delta[tid] = g0 - off0; lcur[tid] = off0; }
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     if (bk[k]) {
-      u32 kk = bk[k] - 1u, b = kk >> pl.LB;
-      u32 q = lstart[b] + atomicAdd(&lcur[b], 1u);
-      stage[q] = (tid + (u32)BS * k) | ((kk & lmask) << 14) | (sg[k] << 21) | (b << 22);
+      u32 kk = (bk[k] & 0x7fffffffu) - 1u, b = kk >> pl.LB;
+      u32 q = atomicAdd(&lcur[b], 1u);
+      stage[q] = (jl0 + jls * (u32)k) | ((kk & lmask) << 14) | ((bk[k] >> 31) << 21) | (b << 22);
     }
   }
   __syncthreads();
@@ -361,8 +398,8 @@ __global__ __launch_bounds__(256) void k_tilemap(GroupPlan pl, const u32* __rest
   u32 end = min(off + pl.T2, bin_start[lo + 1]);
   tile_info[t] = make_uint4(lo, off, end, 1u);
 }
-__device__ __forceinline__ bool locate_tile(const uint4* __restrict__ tile_info, u32& bin, u32& off, u32& end) {
-  uint4 ti = tile_info[blockIdx.x];
+__device__ __forceinline__ bool locate_tile(const uint4* __restrict__ tile_info, u32 t, u32& bin, u32& off, u32& end) {
+  uint4 ti = tile_info[t];
   bin = ti.x; off = ti.y; end = ti.z;
   return ti.w != 0;
 }
@@ -370,21 +407,25 @@ __device__ __forceinline__ bool locate_tile(const uint4* __restrict__ tile_info,
 __global__ __launch_bounds__(256) void k_count2(GroupPlan pl, const u32* __restrict__ entries,
                                                 const uint4* __restrict__ tile_info, u32* __restrict__ bucket_count) {
   __shared__ u32 hist[1u << MAX_LB];
-  u32 bin, off, end;
-  if (!locate_tile(tile_info, bin, off, end)) return;
   const u32 tid = threadIdx.x;
-  if (tid < (1u << MAX_LB)) hist[tid] = 0;
-  __syncthreads();
-  constexpr int PER = STAGE2 / 256;    // T2 <= STAGE2
-  u32 e[PER];
+  // tiles are a prefix of the table; the grid may be smaller than the table (k_binsort takes most bins: few tiles)
+  for (u32 t = blockIdx.x; t < pl.max_tiles; t += gridDim.x) {
+    u32 bin, off, end;
+    if (!locate_tile(tile_info, t, bin, off, end)) return;
+    if (tid < (1u << MAX_LB)) hist[tid] = 0;
+    __syncthreads();
+    constexpr int PER = STAGE2 / 256;    // T2 <= STAGE2
+    u32 e[PER];
 #pragma unroll
-  for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; e[k] = i < end ? entries[i] : 0xffffffffu; }
+    for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; e[k] = i < end ? entries[i] : 0xffffffffu; }
 #pragma unroll
-  for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; if (i < end) atomicAdd(&hist[(e[k] >> 24) & 127u], 1u); }
-  __syncthreads();
-  if (tid < (1u << pl.LB)) {
-    u32 cnt = hist[tid];
-    if (cnt) atomicAdd(&bucket_count[(bin << pl.LB) + tid], cnt);
+    for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; if (i < end) atomicAdd(&hist[(e[k] >> 24) & 127u], 1u); }
+    __syncthreads();
+    if (tid < (1u << pl.LB)) {
+      u32 cnt = hist[tid];
+      if (cnt) atomicAdd(&bucket_count[(bin << pl.LB) + tid], cnt);
+    }
+    __syncthreads();
   }
 }
 
@@ -420,41 +461,44 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
   __shared__ u32 delta[256];          // global position of a bucket's run minus its position in the staging buffer
   __shared__ u32 wsum[4];
   __shared__ u32 stage[STAGE2];       // the pass-1 entry itself: its local-bucket bits say which run it belongs to
-  u32 bin, off, end;
-  if (!locate_tile(tile_info, bin, off, end)) return;
   const u32 tid = threadIdx.x;
-  hist[tid] = 0;
-  __syncthreads();
-  constexpr int PER = STAGE2 / 256;    // T2 <= STAGE2
-  u32 e[PER], rk[PER];
+  for (u32 t = blockIdx.x; t < pl.max_tiles; t += gridDim.x) {     // (see k_count2)
+    u32 bin, off, end;
+    if (!locate_tile(tile_info, t, bin, off, end)) return;
+    hist[tid] = 0;
+    __syncthreads();
+    constexpr int PER = STAGE2 / 256;    // T2 <= STAGE2
+    u32 e[PER], rk[PER];
 #pragma unroll
-  for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; e[k] = i < end ? entries[i] : 0xffffffffu; }
+    for (int k = 0; k < PER; k++) { u32 i = off + tid + 256u * k; e[k] = i < end ? entries[i] : 0xffffffffu; }
 #pragma unroll
-  for (int k = 0; k < PER; k++) {      // the histogram atomic also hands out the rank inside (tile, bucket)
-    u32 i = off + tid + 256u * k;
-    rk[k] = i < end ? atomicAdd(&hist[(e[k] >> 24) & 127u], 1u) : 0u;
-  }
-  __syncthreads();
-  u32 cnt = tid < (1u << pl.LB) ? hist[tid] : 0u;
-  u32 total;
-  u32 o = block_excl_scan_256(cnt, &total, wsum);
-  lstart[tid] = o;
-  if (tid == 255) lstart[256] = total;
-  u32 key = (bin << pl.LB) + tid;
-  delta[tid] = cnt ? bucket_start[key] + atomicAdd(&bucket_cursor[key], cnt) - o : 0u;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PER; k++) {
-    u32 i = off + tid + 256u * k;
-    if (i < end) {
-      u32 l = (e[k] >> 24) & 127u;
-      stage[lstart[l] + rk[k]] = e[k];
+    for (int k = 0; k < PER; k++) {      // the histogram atomic also hands out the rank inside (tile, bucket)
+      u32 i = off + tid + 256u * k;
+      rk[k] = i < end ? atomicAdd(&hist[(e[k] >> 24) & 127u], 1u) : 0u;
     }
-  }
-  __syncthreads();
-  for (u32 q = tid; q < total; q += 256) {
-    u32 v = stage[q];
-    sorted[delta[(v >> 24) & 127u] + q] = v & 0x80ffffffu;
+    __syncthreads();
+    u32 cnt = tid < (1u << pl.LB) ? hist[tid] : 0u;
+    u32 total;
+    u32 o = block_excl_scan_256(cnt, &total, wsum);
+    lstart[tid] = o;
+    if (tid == 255) lstart[256] = total;
+    u32 key = (bin << pl.LB) + tid;
+    delta[tid] = cnt ? bucket_start[key] + atomicAdd(&bucket_cursor[key], cnt) - o : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      u32 i = off + tid + 256u * k;
+      if (i < end) {
+        u32 l = (e[k] >> 24) & 127u;
+        stage[lstart[l] + rk[k]] = e[k];
+      }
+    }
+    __syncthreads();
+    for (u32 q = tid; q < total; q += 256) {
+      u32 v = stage[q];
+      sorted[delta[(v >> 24) & 127u] + q] = v & 0x80ffffffu;
+    }
+    __syncthreads();
   }
 }
 

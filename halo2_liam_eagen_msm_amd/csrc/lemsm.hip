@@ -349,8 +349,8 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t zend = o_arena + (size_t)NBpad * ptb;   // only the bucket sums need zeroing
   size_t o_bin_start = take((MAX_BINS + 1) * 4), o_tile_prefix = take((MAX_BINS + 1) * 4), o_meta = take(64);
   size_t o_bstart = take(((size_t)NBpad + 1) * 4);
-  size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 4);
-  size_t o_dig = take(pl.c ? (size_t)pl.n * (pl.w1 - pl.w0) * 2 + 16 : 16);
+  size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 8);   // per (window, range, bin): counts, then the offsets claimed inside the bin
+  size_t o_dig = take(pl.c ? (size_t)pl.dstride * (pl.w1 - pl.w0) * 2 + 64 : 16);
   size_t o_tinfo = take((size_t)pl.max_tiles * 16 + 16);
   size_t o_sbm = take(pl.c == 17 ? (size_t)(pl.w1 - pl.w0) * ((pl.n + 63) / 64) * 8 + 16 : 16);
   size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
@@ -390,6 +390,7 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   if (n >= (1u << 16) && d == 0 && ctx->opt_stage2x == 4) spb = 4 * STAGE;   // 1024-thread pass-1 blocks staging 16384 entries: 128-byte runs at 512 bins per window
   if (n >= (1u << 16) && d == 0 && ctx->opt_stage2x == 2) spb = 2 * STAGE;   // A/B knob: 64-byte runs at 512 bins per window; measured slower (fewer resident blocks), profiles/r01/y_scatter1_staging_ab.txt
   g.spb = spb;
+  g.dstride = (n + 63u) / 64u * 64u;
   g.nblk1 = (n + spb - 1) / spb;
   if (g.nblk1 == 0) g.nblk1 = 1;
   size_t Mmax = (size_t)n * (w1 - w0);
@@ -508,11 +509,11 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   const u32 xw = (gw >= 8 && ctx->opt_xcd_windows != 1) ? 1u : 0u;
   dim3 g1 = xw ? dim3(8u * ((gw + 7) / 8) * pl.nblk1) : dim3(gw, pl.nblk1);
   if (pl.spb > 2 * STAGE)
-    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 4 * STAGE, 1024>), g1, dim3(1024), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 4 * STAGE, 1024>), g1, dim3(1024), 0, st, dec, pl, w.block_counts, w.bin_start, w.entries, xw);
   else if (pl.spb > STAGE)
-    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 2 * STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 2 * STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.entries, xw);
   else
-    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.bin_cursor, w.entries, xw);
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.entries, xw);
   // pass 2 only where a bin holds more than one bucket (LB > 0); with <= 256 buckets per window
   // (negabase digits) pass 1 already sorts exactly: bins are buckets
   const u32* d_sorted = w.entries;
@@ -520,9 +521,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   if (pl.LB > 0) {
     if (pl.bin_cap) hipLaunchKernelGGL(k_binsort, dim3(pl.nbins), dim3(1024), 0, st, pl, w.entries, w.bin_start, w.sorted, w.bucket_start);
     hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
-    hipLaunchKernelGGL(k_count2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
+    const u32 g2 = pl.bin_cap ? std::min(pl.max_tiles, 2048u) : pl.max_tiles;   // with k_binsort the tiled kernels see the oversize bins only: a small grid walks the (usually empty) tile table
+    hipLaunchKernelGGL(k_count2, dim3(g2), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
     hipLaunchKernelGGL(k_bucketscan, dim3(((pl.nbins << pl.LB) + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
-    hipLaunchKernelGGL(k_scatter2, dim3(pl.max_tiles), dim3(256), 0, st, pl, w.entries, w.tile_info,
+    hipLaunchKernelGGL(k_scatter2, dim3(g2), dim3(256), 0, st, pl, w.entries, w.tile_info,
                        w.bucket_start, w.bucket_cursor, w.sorted);
     d_sorted = w.sorted; d_bstart = w.bucket_start;
   }

@@ -33,6 +33,7 @@ struct GroupPlan {
   uint32_t L1;       // entries per thread in the accumulate kernel
   uint32_t nthr1;    // upper bound on accumulate threads = ceil(n*(w1-w0) / L1)
   uint32_t d;        // negabase: digits per scalar (number of rows of the position-major digit matrix)
+  uint32_t dstride;  // Pippenger: stride of a u16 digit column = n rounded up to 64 (columns start 16-byte aligned for the vector loads of pass 1)
   uint32_t nstride;  // negabase: row stride of the digit matrix = points of the WHOLE call (a slab sees a column range of it)
 };
 
