@@ -373,11 +373,24 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   return w;
 }
 
+// local bucket bits of a pass-1 entry: <= 256 coarse bins per window (512 at nb = 2^16) -- and 512 as well when 256 bins
+// would hold more entries each (n / bins for uniform digits) than one k_binsort block can take: at 2^24 points and
+// 16-bit windows (the window-sharded multi-GPU plan) that halves the bins to 2^15 entries and keeps pass 2 in one block
+u32 choose_lb(const lemsm_ctx* ctx, u32 nb, u32 n, u32 d) {
+  u32 LB = 0;
+  while (((nb + (1u << LB) - 1) >> LB) > 256 && LB < MAX_LB) LB++;
+  if (d == 0 && ctx && ctx->opt_binsort != 2 && LB > 0) {
+    const u32 cap = ctx->opt_binsort > 2 ? std::min((u32)ctx->opt_binsort, (u32)BIN_CAP) : (u32)BIN_CAP;
+    const u32 BW = (nb + (1u << LB) - 1) >> LB;
+    if ((u64)n / BW > (u64)cap * 9 / 10 && 2 * BW <= BW_MAX && (u64)n / (2 * BW) <= (u64)cap * 9 / 10) LB--;
+  }
+  return LB;
+}
+
 GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32 w0, u32 w1, u32 d) {
   GroupPlan g; memset(&g, 0, sizeof g);
   g.n = n; g.c = c; g.nb = nb; g.W = W; g.w0 = w0; g.w1 = w1; g.d = d; g.nstride = n;   // run_windows sets nstride to the call's n
-  u32 LB = 0;
-  while (((nb + (1u << LB) - 1) >> LB) > 256 && LB < MAX_LB) LB++;   // <= 256 coarse bins per window (512 at nb = 2^16)
+  u32 LB = choose_lb(ctx, nb, n, d);
   g.LB = LB;
   g.BW = (nb + (1u << LB) - 1) >> LB;
   g.nbw = g.BW << LB;
@@ -417,9 +430,8 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
 }
 
 // max windows per group: (w1-w0) * BW <= MAX_BINS
-u32 max_group_windows(u32 nb) {
-  u32 LB = 0;
-  while (((nb + (1u << LB) - 1) >> LB) > 256 && LB < MAX_LB) LB++;
+u32 max_group_windows(const lemsm_ctx* ctx, u32 nb, u32 n, u32 d) {
+  u32 LB = choose_lb(ctx, nb, n, d);
   u32 BW = (nb + (1u << LB) - 1) >> LB;
   u32 cap = MAX_BINS / BW;
   return cap == 0 ? 1 : cap;
@@ -714,7 +726,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   if (hs) slab_log = host_slab_log(ctx, n);
   const size_t SLAB = (size_t)1 << slab_log;
   const size_t nslabs = n ? (n + SLAB - 1) / SLAB : 1;
-  u32 gmax = max_group_windows(nb);
+  u32 gmax = max_group_windows(ctx, nb, (u32)std::min(SLAB, n), d);
   const size_t ptb = G::PT_BYTES;
   // Window groups of this call.  Default: as few as the bin limit allows (one at c = 16).  With
   // option "groups" > 1 the sort / accumulate / tail of neighbouring groups run on three queues;
