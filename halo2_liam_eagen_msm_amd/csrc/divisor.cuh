@@ -40,7 +40,7 @@ typedef XYZZ<F> G;
 typedef F::fe fe;
 
 enum { MODE_PASS = 0, MODE_PRODUCT = 1, MODE_DIVIDE = 2 };
-enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_WORDS = 4 };
+enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_MAXCHILD = 3, STAT_ZERO0 = 4, STAT_WORDS = 8 };
 
 // what k_plan decides for one node of the next level
 struct Plan {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_plan(const char* __restrict__ child_xyz
   }
   plan[k] = pl;
   if (panic) atomicOr(&stats[STAT_PANIC], 1u);
-  else atomicMax(&stats[STAT_MAXLEN], max(pl.la, pl.lb));
+  else { atomicMax(&stats[STAT_MAXLEN], max(pl.la, pl.lb)); atomicMax(&stats[STAT_MAXCHILD], max(max(ll.x, ll.y), max(rl.x, rl.y))); }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_load(const u32* __restrict__ cA, const u32* __restrict__ cB, const uint2* __restrict__ child_lens,
                                               u32 ccapA, u32 ccapB, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
-                                              const u32* __restrict__ GP /* g^i */, u32* __restrict__ buf) {
+                                              const u32* __restrict__ GP /* g^i */, u32* __restrict__ buf,
+                                              u32* __restrict__ c0in /* wrap mode: the four constant terms per node, [q][node]; else null */) {
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 per = (u64)nnodes << logN;
   if (gid >= 4 * per) return;
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) void k_load(const u32* __restrict__ cA, const 
     if (have && i) { fe g; ld(g, GP + (size_t)i * 8); F::mul(v, v, g); }   // p(g x): coefficient i times g^i (coset evaluation)
   }
   st(buf + gid * 8, v);
+  if (c0in && i == 0) st(c0in + ((size_t)q * nnodes + k) * 8, v);          // p(0)
 }
 
 // x_i of the (bit-reversed) slot i of a size-N transform: omega_N^rev(i)
@@ -435,9 +437,37 @@ __global__ __launch_bounds__(256) void k_domain(u32 logN, const u32* __restrict_
 // Thread c of a node owns the slots i = c + k * stride (stride = threads per node): the lanes of a wave touch
 // consecutive elements in every trip, and the thread's own N / stride slots share one inversion (Montgomery's trick;
 // the host picks the share: 64 slots when there are millions of elements, fewer when a level is short on threads).
+//
+// Wrap mode (c0in != null).  A node over m = 2^k points has an a-part of m/2 + 1 coefficients: ONE more than a
+// transform of m/2 holds.  Evaluating on the m/2-point coset anyway folds the top coefficient onto the constant term
+// (x^N = g^N on the domain: the inverse transform returns c_0 + g^N c_N at index 0).  The constant term itself is the
+// value at x = 0, which needs only the four constant terms of the children: thread 0 of every node carries that extra
+// "slot" through the same formulas (and the same shared inversion), and k_store unfolds c_N = (t_0 - c_0) g^-N.  Every
+// transform of such a level is half as long.  (No Grumpkin point has x = 0 -- -17 is a non-residue -- so the extra
+// denominator cannot vanish for points on the curve; if it does, STAT_ZERO0 sends the level back to the full size.)
+__device__ __forceinline__ void pw_numerators(fe& A, fe& Bv, fe& den, bool divide, const fe& x, const fe& s,
+                                              const fe& La, const fe& Lb, const fe& Ra, const fe& Rb,
+                                              const fe& c0, const fe& c1, const fe& d0, const fe& lX, const fe& lZZ, const fe& rX, const fe& rZZ, const fe& ninv) {
+  fe t, u;
+  if (divide) {
+    fe l, tA, tB;
+    F::mul(l, c1, x); F::add(l, l, c0);                               // c0 + c1 x
+    F::mul(tA, Ra, l); F::mul(t, Rb, d0); F::mul(t, t, s); F::add(tA, tA, t);     // R.a l + R.b d0 s
+    F::mul(tB, Ra, d0); F::mul(t, Rb, l); F::add(tB, tB, t);                        // R.a d0 + R.b l
+    F::mul(A, La, tA); F::mul(t, Lb, tB); F::mul(t, t, s); F::add(A, A, t);
+    F::mul(Bv, La, tB); F::mul(t, Lb, tA); F::add(Bv, Bv, t);
+    F::mul(t, lZZ, x); F::sub(t, t, lX); F::mul(u, rZZ, x); F::sub(u, u, rX); F::mul(den, t, u);   // (ZZ_L x - X_L)(ZZ_R x - X_R)
+  } else {
+    F::mul(A, La, Ra); F::mul(t, Lb, Rb); F::mul(t, t, s); F::add(A, A, t);
+    F::mul(Bv, La, Rb); F::mul(t, Lb, Ra); F::add(Bv, Bv, t);
+    F::mul(A, A, ninv); F::mul(Bv, Bv, ninv);                          // 1/N of the inverse transform
+    F::set_one(den);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
                                                    const u32* __restrict__ XS, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
-                                                   u32* __restrict__ stats) {
+                                                   u32* __restrict__ stats, const u32* __restrict__ c0in, u32* __restrict__ c0out) {
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (u64)nnodes * stride) return;
@@ -456,31 +486,41 @@ __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const 
   // pass 1: numerators into the L.a / L.b slots, prefix products of the denominators into the R.a slot
   fe run; F::set_one(run);
   for (u32 i = c; i < N; i += stride) {
-    fe x, s, La, Lb, Ra, Rb, A, Bv, t, u;
+    fe x, s, La, Lb, Ra, Rb, A, Bv, den;
     ld(x, XS + (size_t)i * 16); ld(s, XS + (size_t)i * 16 + 8);        // x_i, x_i^3 + B (= y^2)
     ld(La, sLa + (size_t)i * 8); ld(Lb, sLb + (size_t)i * 8); ld(Ra, sRa + (size_t)i * 8); ld(Rb, sRb + (size_t)i * 8);
+    pw_numerators(A, Bv, den, divide, x, s, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, ninv);
     if (divide) {
-      fe l, tA, tB;
-      F::mul(l, c1, x); F::add(l, l, c0);                               // c0 + c1 x
-      F::mul(tA, Ra, l); F::mul(t, Rb, d0); F::mul(t, t, s); F::add(tA, tA, t);     // R.a l + R.b d0 s
-      F::mul(tB, Ra, d0); F::mul(t, Rb, l); F::add(tB, tB, t);                        // R.a d0 + R.b l
-      F::mul(A, La, tA); F::mul(t, Lb, tB); F::mul(t, t, s); F::add(A, A, t);
-      F::mul(Bv, La, tB); F::mul(t, Lb, tA); F::add(Bv, Bv, t);
-      fe den; F::mul(t, lZZ, x); F::sub(t, t, lX); F::mul(u, rZZ, x); F::sub(u, u, rX); F::mul(den, t, u);   // (ZZ_L x - X_L)(ZZ_R x - X_R)
       if (F::is_zero(den)) { atomicOr(&stats[STAT_ZERODEN], 1u); F::set_one(den); }
       st(sRa + (size_t)i * 8, run);                                      // prefix product before this element
       st(sRb + (size_t)i * 8, den);
       F::mul(run, run, den);
-    } else {
-      F::mul(A, La, Ra); F::mul(t, Lb, Rb); F::mul(t, t, s); F::add(A, A, t);
-      F::mul(Bv, La, Rb); F::mul(t, Lb, Ra); F::add(Bv, Bv, t);
-      F::mul(A, A, ninv); F::mul(Bv, Bv, ninv);                          // 1/N of the inverse transform
     }
     st(sLa + (size_t)i * 8, A); st(sLb + (size_t)i * 8, Bv);
+  }
+  // the extra slot x = 0 of wrap mode (thread 0 of the node)
+  const bool extra = c0in != nullptr && c == 0;
+  fe eA, eB, epref, eden;
+  if (extra) {
+    fe x, s, La, Lb, Ra, Rb;
+    F::set_zero(x); ld(s, consts);                                         // 0^3 + b
+    ld(La, c0in + ((size_t)0 * nnodes + k) * 8); ld(Lb, c0in + ((size_t)1 * nnodes + k) * 8);
+    ld(Ra, c0in + ((size_t)2 * nnodes + k) * 8); ld(Rb, c0in + ((size_t)3 * nnodes + k) * 8);
+    pw_numerators(eA, eB, eden, divide, x, s, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, ninv);
+    if (divide) {
+      if (F::is_zero(eden)) { atomicOr(&stats[STAT_ZERO0], 1u); F::set_one(eden); }
+      epref = run;
+      F::mul(run, run, eden);
+    } else { st(c0out + ((size_t)0 * nnodes + k) * 8, eA); st(c0out + ((size_t)1 * nnodes + k) * 8, eB); }
   }
   if (!divide) return;
   // pass 2: Montgomery's trick backwards over the same slots
   fe inv; inv_fast(inv, run);
+  if (extra) {
+    fe di; F::mul(di, inv, epref); F::mul(inv, inv, eden);
+    F::mul(eA, eA, di); F::mul(eB, eB, di);
+    st(c0out + ((size_t)0 * nnodes + k) * 8, eA); st(c0out + ((size_t)1 * nnodes + k) * 8, eB);
+  }
   const u32 cnt = (N - c + stride - 1) / stride;      // slots of this thread
   for (u32 q = cnt; q-- > 0;) {
     const u32 i = c + q * stride;
@@ -496,7 +536,9 @@ __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const 
 __global__ __launch_bounds__(256) void k_store(const u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
                                                const u32* __restrict__ cA, const u32* __restrict__ cB, u32 ccapA, u32 ccapB,
                                                u32* __restrict__ nA, u32* __restrict__ nB, u32 capA, u32 capB, uint2* __restrict__ lens,
-                                               const u32* __restrict__ GI /* g^-i */) {
+                                               const u32* __restrict__ GI /* g^-i */,
+                                               const u32* __restrict__ c0out /* wrap mode: (a(0), b(0)) / N per node, [part][node]; else null */,
+                                               const u32* __restrict__ consts /* [24]: N, [32]: g^-N */) {
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   const u32 cap = max(capA, capB);
   if (gid >= (u64)nnodes * cap) return;
@@ -504,15 +546,31 @@ __global__ __launch_bounds__(256) void k_store(const u32* __restrict__ buf, cons
   const Plan& pl = plan[k];
   if (i == 0) lens[k] = make_uint2(pl.la, pl.lb);
   const size_t per = (size_t)nnodes << logN;
+  const u32 N = 1u << logN;
   fe v;
+  // part `which` (0: a, 1: b) of a merged node, coefficient i: straight from the inverse transform (times g^-i), except
+  // in wrap mode for a part of N + 1 coefficients: c_0 = N * (value at 0 from the extra slot), c_N = (t_0 - c_0) g^-N
+  auto merged = [&](u32 which, u32 len) {
+    const u32* seq = buf + ((size_t)which * per + ((size_t)k << logN)) * 8;
+    if (c0out && len == N + 1 && (i == 0 || i == N)) {
+      fe e, nn, c0v; ld(e, c0out + ((size_t)which * nnodes + k) * 8); ld(nn, consts + 24);
+      F::mul(c0v, e, nn);
+      if (i == 0) { v = c0v; return; }
+      fe t0, gi; ld(t0, seq); ld(gi, consts + 32);
+      F::sub(t0, t0, c0v); F::mul(v, t0, gi);
+      return;
+    }
+    ld(v, seq + (size_t)i * 8);
+    if (i) { fe g; ld(g, GI + (size_t)i * 8); F::mul(v, v, g); }
+  };
   if (i < pl.la) {
     if (pl.mode == MODE_PASS) ld(v, cA + ((size_t)pl.child0 * ccapA + i) * 8);
-    else { ld(v, buf + (((size_t)k << logN) + i) * 8); if (i) { fe g; ld(g, GI + (size_t)i * 8); F::mul(v, v, g); } }
+    else merged(0, pl.la);
     st(nA + ((size_t)k * capA + i) * 8, v);
   }
   if (i < pl.lb) {
     if (pl.mode == MODE_PASS) ld(v, cB + ((size_t)pl.child0 * ccapB + i) * 8);
-    else { ld(v, buf + (per + ((size_t)k << logN) + i) * 8); if (i) { fe g; ld(g, GI + (size_t)i * 8); F::mul(v, v, g); } }
+    else merged(1, pl.lb);
     st(nB + ((size_t)k * capB + i) * 8, v);
   }
 }

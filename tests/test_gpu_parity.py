@@ -1035,6 +1035,25 @@ def test_divisor_witness_matches_reference_restatement(ctx, n):
         assert O.rf_ev(w, O.from_affine(q)) == 0                       # the reference's own assertion, randpoints_witness_test :661
 
 
+@pytest.mark.parametrize("n", [3, 4, 15, 16, 17, 255, 256, 1000, 4095, 4096])
+def test_divisor_witness_half_size_transforms_equal_full_size(ctx, n):
+    """option dw_wrap: a level whose longest part has 2^k + 1 coefficients runs on 2^k-point transforms (top coefficient
+    unfolded from the value at x = 0) -- the same witness, coefficient for coefficient, as with the next power of two"""
+    g = pyref.GRUMPKIN
+    q = cref.gen_points(g.cid, 1700 + n, 1)[0]
+    rows = ctx.gen_walk(g.cid, q, n).download(np.uint64).reshape(-1, 8)
+    res = []
+    try:
+        for mode in (0, 2):
+            ctx.set_option("dw_wrap", mode)
+            a, b, outp = ctx.divisor_witness(api.GRUMPKIN, rows, False, True)
+            res.append((a.copy(), b.copy(), outp.copy()))
+    finally:
+        ctx.set_option("dw_wrap", 0)
+    assert res[0][0].shape == res[1][0].shape and res[0][1].shape == res[1][1].shape
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
+
+
 def test_divisor_witness_10000_points(ctx):
     """the size of randpoints_witness_test (:650-662): 10 000 points (a walk k Q, so that the oracle needs no 10 000 scalar
     multiplications) and minus their sum; full coefficient comparison and the vanishing assertion on a sample"""
