@@ -434,9 +434,9 @@ __global__ __launch_bounds__(256) void k_domain(u32 logN, const u32* __restrict_
   st(XS + (size_t)i * 16, x); st(XS + (size_t)i * 16 + 8, s);
 }
 
-// Thread c of a node owns the slots i = c + k * stride (stride = threads per node): the lanes of a wave touch
-// consecutive elements in every trip, and the thread's own N / stride slots share one inversion (Montgomery's trick;
-// the host picks the share: 64 slots when there are millions of elements, fewer when a level is short on threads).
+// The pointwise step of a level, in two kernels: k_pw_num (numerators and denominators, a thread per slot) and k_pw_inv
+// (a thread per share of slots: one inversion for all of them; the host picks the share: 64 slots when there are
+// millions of elements, fewer when a level is short on threads).
 //
 // Wrap mode (c0in != null).  A node over m = 2^k points has an a-part of m/2 + 1 coefficients: ONE more than a
 // transform of m/2 holds.  Evaluating on the m/2-point coset anyway folds the top coefficient onto the constant term
@@ -465,17 +465,24 @@ __device__ __forceinline__ void pw_numerators(fe& A, fe& Bv, fe& den, bool divid
   }
 }
 
-__global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
-                                                   const u32* __restrict__ XS, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
-                                                   u32* __restrict__ stats, const u32* __restrict__ c0in, u32* __restrict__ c0out) {
+// pass A: one thread per slot (and one per node for the extra slot x = 0 of wrap mode, gid >= nnodes * N): numerators
+// into the L.a / L.b slots, the denominator into the R.b slot.  Nothing here depends on a neighbouring slot, so the loads
+// of a whole wave are in flight together (the one-kernel version walked a thread's slots one after the other at 190
+// VGPRs, two waves per SIMD).
+__global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
+                                                const u32* __restrict__ XS, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
+                                                u32* __restrict__ stats, u32* __restrict__ c0in /* wrap mode, else null; [3][k] receives the extra slot's denominator */,
+                                                u32* __restrict__ c0out) {
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (u64)nnodes * stride) return;
-  const u32 k = (u32)(gid / stride), c = (u32)(gid - (u64)k * stride);
+  const u64 per = (u64)nnodes << logN;
+  const bool extra = gid >= per;
+  if (extra && (c0in == nullptr || gid >= per + nnodes)) return;
+  const u32 k = extra ? (u32)(gid - per) : (u32)(gid >> logN), i = extra ? 0u : ((u32)gid & (N - 1));
   const Plan& pl = plan[k];
   if (pl.mode == MODE_PASS) return;
-  const size_t per = (size_t)nnodes << logN;
-  u32* sLa = buf + (((size_t)k << logN)) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
+  u32* sLa = buf + (((size_t)k << logN) + i) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
+  if (extra) { sLa = c0in + ((size_t)0 * nnodes + k) * 8; sLb = c0in + ((size_t)1 * nnodes + k) * 8; sRa = c0in + ((size_t)2 * nnodes + k) * 8; sRb = c0in + ((size_t)3 * nnodes + k) * 8; }
   fe ninv; ld(ninv, consts + 8);
   fe c0, c1, d0, lX, lZZ, rX, rZZ;
   const bool divide = pl.mode == MODE_DIVIDE;
@@ -483,51 +490,69 @@ __global__ __launch_bounds__(256) void k_pointwise(u32* __restrict__ buf, const 
     ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0); ld(lX, pl.lX); ld(lZZ, pl.lZZ); ld(rX, pl.rX); ld(rZZ, pl.rZZ);
     F::mul(c0, c0, ninv); F::mul(c1, c1, ninv); F::mul(d0, d0, ninv);   // the numerator is linear in the line: 1/N of the inverse transform rides on it
   }
-  // pass 1: numerators into the L.a / L.b slots, prefix products of the denominators into the R.a slot
+  fe x, sv, La, Lb, Ra, Rb, A, Bv, den;
+  if (extra) { F::set_zero(x); ld(sv, consts); }                         // x = 0: 0^3 + b
+  else { ld(x, XS + (size_t)i * 16); ld(sv, XS + (size_t)i * 16 + 8); }  // x_i, x_i^3 + b (= y^2)
+  ld(La, sLa); ld(Lb, sLb); ld(Ra, sRa); ld(Rb, sRb);
+  pw_numerators(A, Bv, den, divide, x, sv, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, ninv);
+  if (divide && F::is_zero(den)) { atomicOr(&stats[extra ? STAT_ZERO0 : STAT_ZERODEN], 1u); F::set_one(den); }
+  if (extra) {
+    st(c0out + ((size_t)0 * nnodes + k) * 8, A); st(c0out + ((size_t)1 * nnodes + k) * 8, Bv);
+    if (divide) st(sRb, den);
+  } else {
+    st(sLa, A); st(sLb, Bv);
+    if (divide) st(sRb, den);
+  }
+}
+
+// pass B (nodes with divisions only): thread c of a node owns the slots i = c + q * stride (consecutive lanes on
+// consecutive elements in every trip) and shares ONE inversion among them (Montgomery's trick): prefix products of the
+// denominators forwards (parked in the R.a slots), inversion, then backwards the inverse of every denominator onto its
+// numerators.  Thread 0 also owns the node's extra slot.
+__global__ __launch_bounds__(256) void k_pw_inv(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
+                                                const u32* __restrict__ c0in, u32* __restrict__ c0out) {
+  const u32 N = 1u << logN;
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (u64)nnodes * stride) return;
+  const u32 k = (u32)(gid / stride), c = (u32)(gid - (u64)k * stride);
+  if (plan[k].mode != MODE_DIVIDE) return;
+  const size_t per = (size_t)nnodes << logN;
+  u32* sLa = buf + (((size_t)k << logN)) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
   fe run; F::set_one(run);
-  for (u32 i = c; i < N; i += stride) {
-    fe x, s, La, Lb, Ra, Rb, A, Bv, den;
-    ld(x, XS + (size_t)i * 16); ld(s, XS + (size_t)i * 16 + 8);        // x_i, x_i^3 + B (= y^2)
-    ld(La, sLa + (size_t)i * 8); ld(Lb, sLb + (size_t)i * 8); ld(Ra, sRa + (size_t)i * 8); ld(Rb, sRb + (size_t)i * 8);
-    pw_numerators(A, Bv, den, divide, x, s, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, ninv);
-    if (divide) {
-      if (F::is_zero(den)) { atomicOr(&stats[STAT_ZERODEN], 1u); F::set_one(den); }
+  {
+    fe nden;                                                             // the next slot's denominator is requested before this slot's product
+    if (c < N) ld(nden, sRb + (size_t)c * 8);
+    for (u32 i = c; i < N; i += stride) {
+      fe den = nden;
+      if (i + stride < N) ld(nden, sRb + (size_t)(i + stride) * 8);
       st(sRa + (size_t)i * 8, run);                                      // prefix product before this element
-      st(sRb + (size_t)i * 8, den);
       F::mul(run, run, den);
     }
-    st(sLa + (size_t)i * 8, A); st(sLb + (size_t)i * 8, Bv);
   }
-  // the extra slot x = 0 of wrap mode (thread 0 of the node)
   const bool extra = c0in != nullptr && c == 0;
-  fe eA, eB, epref, eden;
-  if (extra) {
-    fe x, s, La, Lb, Ra, Rb;
-    F::set_zero(x); ld(s, consts);                                         // 0^3 + b
-    ld(La, c0in + ((size_t)0 * nnodes + k) * 8); ld(Lb, c0in + ((size_t)1 * nnodes + k) * 8);
-    ld(Ra, c0in + ((size_t)2 * nnodes + k) * 8); ld(Rb, c0in + ((size_t)3 * nnodes + k) * 8);
-    pw_numerators(eA, eB, eden, divide, x, s, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, ninv);
-    if (divide) {
-      if (F::is_zero(eden)) { atomicOr(&stats[STAT_ZERO0], 1u); F::set_one(eden); }
-      epref = run;
-      F::mul(run, run, eden);
-    } else { st(c0out + ((size_t)0 * nnodes + k) * 8, eA); st(c0out + ((size_t)1 * nnodes + k) * 8, eB); }
-  }
-  if (!divide) return;
-  // pass 2: Montgomery's trick backwards over the same slots
+  fe epref, eden;
+  if (extra) { ld(eden, c0in + ((size_t)3 * nnodes + k) * 8); epref = run; F::mul(run, run, eden); }
   fe inv; inv_fast(inv, run);
   if (extra) {
-    fe di; F::mul(di, inv, epref); F::mul(inv, inv, eden);
-    F::mul(eA, eA, di); F::mul(eB, eB, di);
-    st(c0out + ((size_t)0 * nnodes + k) * 8, eA); st(c0out + ((size_t)1 * nnodes + k) * 8, eB);
+    fe di, A, Bv; F::mul(di, inv, epref); F::mul(inv, inv, eden);
+    ld(A, c0out + ((size_t)0 * nnodes + k) * 8); ld(Bv, c0out + ((size_t)1 * nnodes + k) * 8);
+    F::mul(A, A, di); F::mul(Bv, Bv, di);
+    st(c0out + ((size_t)0 * nnodes + k) * 8, A); st(c0out + ((size_t)1 * nnodes + k) * 8, Bv);
   }
-  const u32 cnt = (N - c + stride - 1) / stride;      // slots of this thread
+  const u32 cnt = c < N ? (N - c + stride - 1) / stride : 0u;      // slots of this thread
+  fe npref, nden, nA, nB;                                // operands of the next slot down, requested one slot ahead
+  if (cnt) {
+    const u32 i = c + (cnt - 1) * stride;
+    ld(npref, sRa + (size_t)i * 8); ld(nden, sRb + (size_t)i * 8); ld(nA, sLa + (size_t)i * 8); ld(nB, sLb + (size_t)i * 8);
+  }
   for (u32 q = cnt; q-- > 0;) {
     const u32 i = c + q * stride;
-    fe pref, den, di, A, Bv;
-    ld(pref, sRa + (size_t)i * 8); ld(den, sRb + (size_t)i * 8);
+    fe pref = npref, den = nden, A = nA, Bv = nB, di;
+    if (q) {
+      const u32 j = i - stride;
+      ld(npref, sRa + (size_t)j * 8); ld(nden, sRb + (size_t)j * 8); ld(nA, sLa + (size_t)j * 8); ld(nB, sLb + (size_t)j * 8);
+    }
     F::mul(di, inv, pref); F::mul(inv, inv, den);
-    ld(A, sLa + (size_t)i * 8); ld(Bv, sLb + (size_t)i * 8);
     F::mul(A, A, di); F::mul(Bv, Bv, di);
     st(sLa + (size_t)i * 8, A); st(sLb + (size_t)i * 8, Bv);
   }
