@@ -257,9 +257,12 @@ def main():
 
 def pmc_traffic(workload, curve, logn, world):
     """HBM bytes per k_accum1 launch from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC cannot be collected from inside
-    the process, so the figure is looked up for the exact workload and is null otherwise."""
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, tools/pmc_refresh.sh and
+    tools/pmc_traffic.py; the gfx950 FETCH_SIZE doubling of MI355X_MICROARCH.md is NOT applied: it holds for wide
+    coalesced streams, this kernel gathers 64-byte rows -- calibration in profiles/r01/fetch_size_calibration.txt).
+    N > 1 entries were measured on ONE GPU running the ranks' pipelines one after the other (each entry says so).
+    PMC cannot be collected from inside the process, so the figure is looked up for the exact workload and is
+    null otherwise."""
     path = os.path.join(ROOT, "profiles", "traffic_accum1.json")
     try:
         table = json.load(open(path))
