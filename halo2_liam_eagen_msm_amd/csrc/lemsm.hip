@@ -103,6 +103,7 @@ struct lemsm_ctx {
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   std::string last_error;
   long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0;
+  u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -377,6 +378,9 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
 // would hold more entries each (n / bins for uniform digits) than one k_binsort block can take: at 2^24 points and
 // 16-bit windows (the window-sharded multi-GPU plan) that halves the bins to 2^15 entries and keeps pass 2 in one block
 u32 choose_lb(const lemsm_ctx* ctx, u32 nb, u32 n, u32 d) {
+  // one geometry per call: a ragged last slab must not pick MORE bins per window than the full slabs the window groups
+  // were sized for (found by the fuzz soak with a 3-entry test capacity: 20 windows x 512 bins > MAX_BINS)
+  if (ctx && ctx->plan_slab_n) n = ctx->plan_slab_n;
   u32 LB = 0;
   while (((nb + (1u << LB) - 1) >> LB) > 256 && LB < MAX_LB) LB++;
   if (d == 0 && ctx && ctx->opt_binsort != 2 && LB > 0) {
@@ -510,6 +514,9 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   CopyTask* d_copy = (CopyTask*)((char*)pit->second.buf.p + align_up(ntasks_total * sizeof(PyrTask), 256));
   const size_t ptb = G::PT_BYTES;
   GroupWs w = carve(ws_base, pl, ar, ntasks_total, ptb, ctx->opt_ws_canary != 0);
+  // the kernels below size LDS arrays and workspace slots by these limits: never launch a plan that exceeds them
+  if (pl.nbins > MAX_BINS || pl.BW > BW_MAX || pl.LB > MAX_LB || pl.spb > 4 * STAGE || (pl.c && pl.dstride < pl.n) || pl.T2 > STAGE2 || pl.bin_cap > BIN_CAP)
+    return fail(ctx, LEMSM_ERR_HIP, "internal: window-group plan exceeds a kernel limit (bins " + std::to_string(pl.nbins) + ", bins per window " + std::to_string(pl.BW) + ")");
 
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
   for (size_t g : w.guards) HIPCHK(ctx, hipMemsetAsync(ws_base + g, 0xA5, WS_GUARD, st));
@@ -726,7 +733,8 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   if (hs) slab_log = host_slab_log(ctx, n);
   const size_t SLAB = (size_t)1 << slab_log;
   const size_t nslabs = n ? (n + SLAB - 1) / SLAB : 1;
-  u32 gmax = max_group_windows(ctx, nb, (u32)std::min(SLAB, n), d);
+  ctx->plan_slab_n = (u32)std::min(SLAB, n);
+  u32 gmax = max_group_windows(ctx, nb, ctx->plan_slab_n, d);
   const size_t ptb = G::PT_BYTES;
   // Window groups of this call.  Default: as few as the bin limit allows (one at c = 16).  With
   // option "groups" > 1 the sort / accumulate / tail of neighbouring groups run on three queues;

@@ -200,7 +200,25 @@ def main(secs=None, seed=None):
             what = "lhs base %d" % base
         ok = cref.jac_to_canonical(curve.cid, np.ascontiguousarray(got, np.uint64)) == cref.jac_to_canonical(curve.cid, exp)
         if not ok:
-            print("MISMATCH seed=%d case=%d %s %s n=%d shape=%s opts=%s" % (seed, cases, what, curve.name, n, shape, opts), flush=True)
+            print("MISMATCH seed=%d case=%d %s %s n=%d shape=%s host_entry=%s sharded=%s world=%d opts=%s" % (seed, cases, what, curve.name, n, shape, host_entry, sharded, world, opts), flush=True)
+            if what == "msm" and os.environ.get("FUZZ_BISECT"):
+                # which single option, put back to its default, makes the same inputs come out right?
+                def run():
+                    if host_entry:
+                        return ctx.msm(curve.cid, sc, pts)
+                    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+                    return ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, world) if sharded else ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)
+                want = cref.jac_to_canonical(curve.cid, exp)
+                for k in names:
+                    if not opts[k]:
+                        continue
+                    ctx.set_option(k, 0)
+                    try:
+                        good = cref.jac_to_canonical(curve.cid, np.ascontiguousarray(run(), np.uint64)) == want
+                    except Exception as ex:
+                        good = "exception %r" % (ex,)
+                    print("  with %s = 0 (was %d): %s" % (k, opts[k], good), flush=True)
+                    ctx.set_option(k, opts[k])
             sys.exit(1)
         cases += 1
         if cases % 50 == 0:
