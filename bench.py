@@ -75,7 +75,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["msm", "lhs"], default="msm")
+    ap.add_argument("--workload", choices=["msm", "lhs", "lhs_witness"], default="msm",
+                    help="msm: best_multiexp (the headline); lhs: the MSM core of compute_lhs_witness; lhs_witness: compute_lhs_witness in full "
+                         "(carry + the d divisor witnesses, Grumpkin, SURVEY 8 row f2), one GPU")
     ap.add_argument("--logn", type=int, default=None)
     ap.add_argument("--curve", choices=["bn254_g1", "grumpkin"], default="bn254_g1")
     ap.add_argument("--base", type=int, default=16)
@@ -96,8 +98,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    logn = args.logn if args.logn is not None else (24 if args.workload == "msm" else 20)
+    logn = args.logn if args.logn is not None else (24 if args.workload == "msm" else (18 if args.workload == "lhs_witness" else 20))
     n = 1 << logn
+    if args.workload == "lhs_witness":
+        if world != 1:
+            raise SystemExit("--workload lhs_witness is a one-GPU line (the d trees of a call would shard by digit position with no exchange; not built)")
+        return bench_lhs_witness(args, n, logn)
 
     import torch
     import torch.distributed as dist
@@ -253,6 +259,165 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+BUTTERFLY_PEAK = 115e9   # ~1200 issue cycles per wave-butterfly (strict 8x32-bit Montgomery product + add + sub) on 1024 SIMDs at 2.1 GHz
+
+
+def bench_lhs_witness(args, n, logn):
+    """compute_lhs_witness in full (src/argument_witness_calc.rs:87-136: the carry AND the d divisor witnesses), Grumpkin,
+    scalars / affine points resident in HBM and the coefficients left in HBM (lemsm_lhs_witness_device).  One JSON line of
+    the same shape as the MSM workloads; `roofline` prices the transform launches of the merge forest (device time from
+    HIP events inside the library, algorithmic bytes = one read + one write of every 32-byte element per pass over HBM)."""
+    import torch
+    from halo2_liam_eagen_msm_amd import Context, DeviceBuffer, num_digits
+    torch.cuda.set_device(0)
+    ctx = Context(0)
+    cid, curve = 1, "grumpkin"
+    order = ORDER[curve]; fp = ORDER["bn254_g1"]
+    scalars = gen_scalars(n, math.isqrt(order), 0x5EED1000 + logn)
+    d_scalars = ctx.to_device(scalars)
+    q = np.zeros(8, np.uint64)
+    gx, gy = 1, 0x2CF135E7506A45D632D270D45F1181294833FC48D823F272C
+    q[:4] = np.frombuffer(((gx << 256) % fp).to_bytes(32, "little"), np.uint64)
+    q[4:] = np.frombuffer(((gy << 256) % fp).to_bytes(32, "little"), np.uint64)
+    d_points = ctx.gen_walk(cid, q, n)
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        ctx.set_option(name, int(val))
+    d = num_digits(cid, args.base)
+    out = DeviceBuffer(ctx, 2 * d * (n + args.base + 3) * 32)
+
+    def step():
+        return ctx.lhs_witness_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True, out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ntt_ms = 0.0; ntt_bytes = 0; ntt_bf = 0; phases = np.zeros(4)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        carry, index, _ = step()
+        ms, by, bf = ctx.divisor_last_ntt()
+        ntt_ms += ms; ntt_bytes += by; ntt_bf += bf
+        phases += np.array(ctx.lhs_witness_last_phases())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / args.steps * 1e3
+    achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
+    coeffs = int(index[:, 1].sum() + index[:, 3].sum())
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel": "k_ntt_tile (forward and inverse transforms of the merge forest, all levels of one call)",
+                "kernel_ms": round(ntt_ms / args.steps, 3), "algorithmic_bytes_per_step": ntt_bytes // args.steps,
+                "note": "LDS-tiled transforms are bound by the field multiplication, not by HBM (DESIGN.md section 6): butterflies/s against the VALU ceiling below",
+                "valu_butterflies": {"achieved_G_s": round(ntt_bf / (ntt_ms * 1e-3) / 1e9, 1) if ntt_ms > 0 else 0.0, "peak_G_s": BUTTERFLY_PEAK / 1e9,
+                                     "frac": round(ntt_bf / (ntt_ms * 1e-3) / BUTTERFLY_PEAK, 4) if ntt_ms > 0 else 0.0,
+                                     "model": "model-derived peak: ~1200 issue cycles per wave-butterfly x 1024 SIMDs at 2.1 GHz"},
+                "phases_ms": {k: round(float(v) / args.steps, 2) for k, v in zip(("msm_core", "point_lists", "merge_forest", "coefficient_copy"), phases)}}
+    checks = verify_lhs_witness(ctx, cid, scalars, q, d_points, n, args.base, carry, index, out)
+    res = {"metric": "Grumpkin compute_lhs_witness scalar-point-pairs/s (carry + %d divisor witnesses)" % d, "value": round(n * args.steps / elapsed, 1), "unit": "pairs/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
+           "config": {"workload": "grumpkin compute_lhs_witness in full, 2^%d points, negabase B=%d, half-width scalars" % (logn, args.base), "n": n, "curve": curve,
+                      "coefficients_per_step": coeffs, "baseline_config": "SURVEY section 8 row f2 (the second return value of compute_lhs_witness); no BASELINE.json config names it",
+                      "io": "scalars and affine points resident in HBM, coefficients left in HBM (lemsm_lhs_witness_device)"},
+           "roofline": roofline}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_lhs_witness(ctx, cid, scalars, d_points, args)
+        checks.append("sample vs oracle (every coefficient of every function)")
+    if args.option:
+        res["config"]["options"] = args.option
+    res["config"]["bit_exact"] = True if checks else None
+    res["config"]["bit_exact_checks"] = checks
+    print(json.dumps(res), flush=True)
+
+
+def verify_lhs_witness(ctx, cid, scalars, q, d_points, n, base, carry, index, out):
+    """Checker leg for the timed compute_lhs_witness result: the carry against the closed form of the synthetic input, the
+    shape of every function, and the property the reference's own test asserts (randpoints_witness_test :661): a function
+    vanishes on the points of its list -- checked for one digit position on a multiple d_j P_j picked from the digits the
+    oracle computes for a few scalars, by Horner evaluation in Python integers."""
+    from oracle import cref, pyref
+    exp = cref.jac_to_canonical(cid, cref.scalar_mul(cid, cref.walk_dot(cid, scalars), q))
+    if cref.jac_to_canonical(cid, np.ascontiguousarray(carry, np.uint64)) != exp:
+        raise SystemExit("the timed compute_lhs_witness carry differs from the closed form of the synthetic input: parity broken")
+    checks = ["timed carry vs walk identity"]
+    g = pyref.GRUMPKIN; p = g.fp
+    d = index.shape[0]
+    for f in range(d):
+        oa, la, ob, lb = (int(v) for v in index[f])
+        if not (la + lb >= 1 and la + lb <= 2 * (n + base + 3)):
+            raise SystemExit("function %d has an impossible shape (%d, %d)" % (f, la, lb))
+    rinv = pow(1 << 256, -1, p)
+    qa = g.raw_to_affine(q.tobytes())
+    digs = {j: pyref.negbase_digits_padded(int.from_bytes(scalars[j].tobytes(), "little"), base, d) for j in (0, 1, n // 2, n - 1)}   # LSB first
+    done = 0
+    for pos in range(d):
+        js = [j for j, dg in digs.items() if dg[pos]]
+        if not js or done >= 2:
+            continue
+        f = pos                                        # function f belongs to digit iteration i = d - 1 - f, which handles position d - 1 - i = f (LSB-first index)
+        oa, la, ob, lb = (int(v) for v in index[f])
+        a = _download_elems(ctx, out, oa, la); b = _download_elems(ctx, out, ob, lb)
+        for j in js[:2]:
+            pt = g.mul(digs[j][pos] * (j + 1) % g.order, qa)
+            x, y = pt
+            va = 0
+            for k in range(la - 1, -1, -1):
+                va = (va * x + int.from_bytes(a[k].tobytes(), "little")) % p
+            vb = 0
+            for k in range(lb - 1, -1, -1):
+                vb = (vb * x + int.from_bytes(b[k].tobytes(), "little")) % p
+            if (va + y * vb) * rinv % p != 0:
+                raise SystemExit("function %d does not vanish on %d * P_%d: parity broken" % (f, digs[j][pos], j))
+        done += 1
+    if done:
+        checks.append("witness vanishes on sampled points of its list (%d digit positions)" % done)
+    return checks
+
+
+def _download_elems(ctx, buf, off_elems, count):
+    """count 32-byte elements of a DeviceBuffer starting at element off_elems, as (count, 4) u64"""
+    import ctypes
+    outa = np.empty((count, 4), np.uint64)
+    if count:
+        ctx._check(ctx.lib.lemsm_device_download(ctx.h, outa.ctypes.data_as(ctypes.c_void_p), buf.ptr + off_elems * 32, count * 32))
+    return outa
+
+
+def cpu_baseline_lhs_witness(ctx, cid, scalars, d_points, args):
+    """Oracle leg: compute_lhs_witness of a bounded sample through the big-int restatement of the reference (oracle/divisor.py:
+    serial group arithmetic, Kronecker-substitution polynomial products), one thread, timed; the GPU result on the same
+    sample compared function by function, coefficient by coefficient (after normalising the coefficient of highest pole
+    order, a RegularFunction being defined up to a scalar)."""
+    import json as _json
+    from oracle import pyref, divisor as dv
+    g = pyref.GRUMPKIN; p = g.fp
+    slog = args.cpu_sample_log if args.cpu_sample_log is not None else 9
+    m = 1 << slog
+    head = int.from_bytes(bytes.fromhex(_json.load(open(os.path.join(ROOT, "tests", "golden", "fr_mont_chains.json")))["omega_pow"]["head"]), "little")
+    O = dv.DivisorOracle(g, dv.FrFft(p, head * pow(1 << 256, -1, p) % p))
+    rows = d_points.download(np.uint64, m * 64).reshape(-1, 8)
+    pts = [O.from_affine(g.raw_to_affine(rows[i].tobytes())) for i in range(m)]
+    sc = [int.from_bytes(scalars[i].tobytes(), "little") for i in range(m)]
+    t0 = time.perf_counter()
+    ecarry, efns = dv.compute_lhs_witness(O, sc, pts, args.base)
+    dt = time.perf_counter() - t0
+    ds = ctx.to_device(np.ascontiguousarray(scalars[:m]))
+    carry, index, out = ctx.lhs_witness_device(cid, ds.ptr, d_points.ptr, m, args.base, True)
+    rinv = pow(1 << 256, -1, p)
+    from oracle import cref
+    if cref.jac_to_canonical(cid, np.ascontiguousarray(carry, np.uint64)) != g.canonical(O.to_affine(ecarry)):
+        raise SystemExit("GPU carry differs from the CPU oracle on the sample: parity broken")
+    for f, exp in enumerate(efns):
+        oa, la, ob, lb = (int(v) for v in index[f])
+        e = O.normalise(exp)
+        ga = [int.from_bytes(r.tobytes(), "little") * rinv % p for r in _download_elems(ctx, out, oa, la)]
+        gb = [int.from_bytes(r.tobytes(), "little") * rinv % p for r in _download_elems(ctx, out, ob, lb)]
+        if (ga, gb) != e:
+            raise SystemExit("GPU divisor witness %d differs from the CPU oracle on the sample: parity broken" % f)
+    return {"value": round(m / dt, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "first 2^%d pairs of the same inputs, compute_lhs_witness restatement (oracle/divisor.py, Python big integers, serial), %.2f s, GPU result on the sample: carry and all %d functions equal" % (slog, dt, len(efns))}
 
 
 def pmc_traffic(workload, curve, logn, world):

@@ -390,6 +390,27 @@ class Context:
             fns.append((coeffs[oa: oa + la], coeffs[ob: ob + lb]))
         return carry, fns
 
+    def lhs_witness_device(self, curve, d_scalars: int, d_points_affine: int, n: int, base: int, normalise: bool = True,
+                           out: Optional[DeviceBuffer] = None):
+        """compute_lhs_witness in full with scalars / affine points resident in HBM and the coefficients left there:
+        (carry, index[d, 4] = {offset_a, len_a, offset_b, len_b} in 32-byte elements, DeviceBuffer of the coefficients).
+        `out`: a buffer of at least 2 d (n + base + 3) elements to reuse across calls."""
+        cid = _curve_id(curve)
+        if not (3 <= base <= 255):
+            raise BadBase(_lib.LEMSM_ERR_BAD_BASE, "base must be in 3..=255")
+        d = num_digits(cid, base)
+        cap = 2 * d * (n + base + 3)
+        if out is None:
+            out = DeviceBuffer(self, cap * 32)
+        assert out.nbytes >= cap * 32
+        index = np.zeros((d, 4), np.uintp)
+        carry = np.zeros(12, np.uint64)
+        bad = ctypes.c_size_t(0)
+        rc = self.lib.lemsm_lhs_witness_device(self.h, cid, d_scalars, d_points_affine, n, base, _ptr(carry), out.ptr, cap,
+                                               index.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), int(normalise), ctypes.byref(bad))
+        self._check(rc, bad.value)
+        return carry, index, out
+
     def debug_ntt(self, data, logn: int, inverse: bool = False) -> np.ndarray:
         a = _limbs(data, 4)
         assert a.shape[0] % (1 << logn) == 0

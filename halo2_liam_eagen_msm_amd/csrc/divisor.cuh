@@ -658,6 +658,18 @@ __global__ __launch_bounds__(256) void k_lhs_gather(const uint8_t* __restrict__ 
   uint4* o = out + ((size_t)lead + offs[j]) * 4;
   o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
 }
+// affine rows (64 B, (0,0) = identity) -> Jacobian rows (96 B, z = 1 in Montgomery form, identity = zeros)
+__global__ __launch_bounds__(256) void k_aff_to_jac(const uint4* __restrict__ aff, u32 n, uint4* __restrict__ jac) {
+  u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint4 a0 = aff[(size_t)i * 4], a1 = aff[(size_t)i * 4 + 1], a2 = aff[(size_t)i * 4 + 2], a3 = aff[(size_t)i * 4 + 3];
+  const bool id = (a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w | a2.x | a2.y | a2.z | a2.w | a3.x | a3.y | a3.z | a3.w) == 0;
+  fe one; F::set_one(one);
+  uint4 z0 = id ? make_uint4(0, 0, 0, 0) : make_uint4(one.v[0], one.v[1], one.v[2], one.v[3]);
+  uint4 z1 = id ? make_uint4(0, 0, 0, 0) : make_uint4(one.v[4], one.v[5], one.v[6], one.v[7]);
+  uint4* o = jac + (size_t)i * 6;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = z0; o[5] = z1;
+}
 // out[i] = pt for i < count (the `base` copies of -carry, :112-116) ; and single-slot writes
 __global__ __launch_bounds__(256) void k_fill_points(const uint4* __restrict__ pt, u32 count, uint4* __restrict__ out) {
   u32 i = blockIdx.x * 256 + threadIdx.x;

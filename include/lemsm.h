@@ -280,6 +280,13 @@ int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithm
 int lemsm_lhs_witness(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* pts_jacobian, size_t n,
                       uint8_t base, uint64_t out_carry[12], uint64_t* out_coeffs, size_t cap_coeffs, size_t* out_index,
                       int normalise, size_t* bad_index);
+/* The same with the scalars and the AFFINE points (64-byte rows, as the device-pointer MSM entries take them) already in
+   HBM and the coefficients left in HBM (d_out_coeffs: device buffer of cap_coeffs 32-byte elements); carry and index
+   come back to the host.  For a prover that goes on to commit to the witness on the GPU, and the form bench.py times
+   (--workload lhs_witness: inputs and outputs resident). */
+int lemsm_lhs_witness_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine, size_t n,
+                             uint8_t base, uint64_t out_carry[12], void* d_out_coeffs, size_t cap_coeffs, size_t* out_index,
+                             int normalise, size_t* bad_index);
 /* Host-clock milliseconds of the four phases of the last lemsm_lhs_witness call (each ends on a stream synchronise):
    [0] the MSM core (upload of scalars and points, digits, buckets, carries), [1] the table of multiples and the d point
    lists, [2] the merge forest (every field operation of the divisor witnesses), [3] the download of the coefficients

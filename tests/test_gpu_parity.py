@@ -1159,6 +1159,32 @@ def test_compute_lhs_witness_full_return_value(ctx, base, n):
         assert (_from_mont(got[0], p), _from_mont(got[1], p)) == e, f
 
 
+@pytest.mark.parametrize("base,n", [(5, 37), (16, 300)])
+def test_lhs_witness_device_entry_equals_host_entry(ctx, base, n):
+    """lemsm_lhs_witness_device (scalars and affine points in HBM, coefficients left in HBM) returns what lemsm_lhs_witness
+    does for the same points handed over as host Jacobian rows: carry, index and every coefficient"""
+    g = pyref.GRUMPKIN
+    rng = pyref.SplitMix64(2600 + base + n)
+    sc = pyref.gen_scalars_half(rng, n, g.order)
+    scb = np.frombuffer(pyref.scalars_to_bytes(sc), np.uint8).reshape(-1, 32)
+    q = cref.gen_points(g.cid, 2601, 1)[0]
+    dp = ctx.gen_walk(g.cid, q, n)
+    aff = dp.download(np.uint64).reshape(-1, 8)
+    aff[3] = 0                                              # an identity among the points
+    dp.upload(aff)
+    jac = cref.aff_to_jac(g.cid, aff)
+    carry_h, fns = ctx.lhs_witness(g.cid, scb, jac, base, True)
+    ds = ctx.to_device(scb)
+    carry_d, index, out = ctx.lhs_witness_device(g.cid, ds.ptr, dp.ptr, n, base, True)
+    assert canon(g, carry_d) == canon(g, carry_h)
+    flat = out.download(np.uint64).reshape(-1, 4)
+    assert index.shape[0] == len(fns)
+    for f, (a, b) in enumerate(fns):
+        oa, la, ob, lb = (int(v) for v in index[f])
+        assert (la, lb) == (a.shape[0], b.shape[0]), f
+        assert (flat[oa: oa + la] == a).all() and (flat[ob: ob + lb] == b).all(), f
+
+
 def test_divisor_witness_2p20_vanishes_on_its_points(ctx):
     """full size (the point count of configs[1]'s per-digit lists): 2^20 walk points k Q and minus their sum
     (n (n + 1) / 2 Q); the size-independent property the reference asserts (randpoints_witness_test :661): the
