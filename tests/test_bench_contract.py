@@ -52,3 +52,25 @@ def test_bench_prints_one_contract_line(extra):
     assert ("compute_lhs_witness" in cb["sample"]) == (extra != [])
     if extra:
         assert cb["cores"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_lhs_witness_line():
+    """--workload lhs_witness: compute_lhs_witness in full as a contract-shaped, self-verified line"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "lhs_witness", "--steps", "2", "--warmup", "1", "--logn", "10",
+           "--cpu-sample-log", "7"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["unit"] == "pairs/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None
+    assert d["config"]["bit_exact"] is True and "timed carry vs walk identity" in d["config"]["bit_exact_checks"]
+    assert any("every coefficient" in c for c in d["config"]["bit_exact_checks"])
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and ro["traffic"] is None
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and "k_ntt_tile" in ro["kernel"] and ro["kernel_ms"] > 0
+    assert 0 < ro["valu_butterflies"]["frac"] <= 1.0
+    assert set(ro["phases_ms"]) == {"msm_core", "point_lists", "merge_forest", "coefficient_copy"}
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "compute_lhs_witness" in cb["sample"]
