@@ -394,6 +394,7 @@ def cpu_baseline_lhs_witness(ctx, cid, scalars, d_points, args):
     from oracle import pyref, divisor as dv
     g = pyref.GRUMPKIN; p = g.fp
     slog = args.cpu_sample_log if args.cpu_sample_log is not None else 12      # ~10-20 s of the Python restatement
+    slog = min(slog, int(math.log2(scalars.shape[0])))
     m = 1 << slog
     head = int.from_bytes(bytes.fromhex(_json.load(open(os.path.join(ROOT, "tests", "golden", "fr_mont_chains.json")))["omega_pow"]["head"]), "little")
     O = dv.DivisorOracle(g, dv.FrFft(p, head * pow(1 << 256, -1, p) % p))
