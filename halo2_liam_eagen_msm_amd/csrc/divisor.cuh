@@ -40,7 +40,7 @@ typedef XYZZ<F> G;
 typedef F::fe fe;
 
 enum { MODE_PASS = 0, MODE_PRODUCT = 1, MODE_DIVIDE = 2 };
-enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_MAXCHILD = 3, STAT_ZERO0 = 4, STAT_WORDS = 8 };
+enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_MAXCHILD = 3, STAT_ZERO0 = 4, STAT_MAXPASS = 5, STAT_WORDS = 8 };
 
 // what k_plan decides for one node of the next level
 struct Plan {
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void k_plan(const char* __restrict__ child_xyz
   uint2 ll = child_lens[L];
   if (nch < 2) {                                      // MaybePair::Unit: passes through unchanged (:363-366)
     pl.mode = MODE_PASS; pl.la = ll.x; pl.lb = ll.y;
+    atomicMax(&stats[STAT_MAXPASS], max(ll.x, ll.y));
     plan[k] = pl;
     return;
   }
@@ -324,9 +325,61 @@ __global__ __launch_bounds__(256) void k_ntt_stage(u32* __restrict__ buf, u32 ns
 //   lo  > 0 : stages with spans 2^(lo+S-1)..2^lo: a tile is 2^S positions 2^lo apart, TW = 1024 >> S neighbouring
 //             tiles side by side so that every access is a run of TW consecutive elements.
 // Forward (DIF) runs the strided passes from the top spans down, then the contiguous pass; inverse (DIT) the reverse.
-template <bool INV>
+// What the first forward pass reads and the last inverse pass writes when the level's load / store steps are fused into
+// the transforms (k_load / k_store below are the unfused forms and say what each field means).
+struct TileIO {
+  const u32* cA; const u32* cB; const uint2* child_lens; u32 ccapA, ccapB; const Plan* plan; u32 nnodes; const u32* GP; u32* c0in;      // load side
+  u32* nA; u32* nB; u32 capA, capB; uint2* lens; const u32* GI; const u32* c0out; const u32* consts;                                      // store side
+};
+// element g = (q * nnodes + k) * N + i of the forward input: coefficient i of child part q of node k, times g^i (k_load)
+__device__ __forceinline__ void tile_load_coeff(fe& v, const TileIO& io, u64 g, u32 logN) {
+  const u64 per = (u64)io.nnodes << logN;
+  const u32 q = (u32)(g / per); const u64 rem = g - (u64)q * per;
+  const u32 k = (u32)(rem >> logN), i = (u32)rem & ((1u << logN) - 1);
+  F::set_zero(v);
+  if (io.plan[k].mode != MODE_PASS) {
+    const u32 c = io.plan[k].child0 + (q >> 1);
+    const uint2 cl = io.child_lens[c];
+    bool have = false;
+    if (q & 1) { if (i < cl.y) { ld(v, io.cB + ((size_t)c * io.ccapB + i) * 8); have = true; } }
+    else { if (i < cl.x) { ld(v, io.cA + ((size_t)c * io.ccapA + i) * 8); have = true; } }
+    if (have && i) { fe gp; ld(gp, io.GP + (size_t)i * 8); F::mul(v, v, gp); }
+  }
+  if (io.c0in && i == 0) st(io.c0in + ((size_t)q * io.nnodes + k) * 8, v);
+}
+// element g = (which * nnodes + k) * N + i of the inverse output -> coefficient i of part `which` of node k (k_store);
+// requires every length of the level <= N (N + 1 in wrap mode): the host checks STAT_MAXLEN / STAT_MAXPASS
+__device__ __forceinline__ void tile_store_coeff(const fe& t, const TileIO& io, u64 g, u32 logN) {
+  const u32 N = 1u << logN;
+  const u64 per = (u64)io.nnodes << logN;
+  const u32 which = (u32)(g / per); const u64 rem = g - (u64)which * per;
+  const u32 k = (u32)(rem >> logN), i = (u32)rem & (N - 1);
+  const Plan& pl = io.plan[k];
+  if (which == 0 && i == 0) io.lens[k] = make_uint2(pl.la, pl.lb);
+  const u32 len = which ? pl.lb : pl.la;
+  u32* dst = (which ? io.nB : io.nA) + (size_t)k * (which ? io.capB : io.capA) * 8;
+  if (pl.mode == MODE_PASS) {
+    if (i < len) { fe v; ld(v, (which ? io.cB + (size_t)pl.child0 * io.ccapB * 8 : io.cA + (size_t)pl.child0 * io.ccapA * 8) + (size_t)i * 8); st(dst + (size_t)i * 8, v); }
+    return;
+  }
+  if (io.c0out && len == N + 1 && i == 0) {          // wrap mode: c_0 = N * (value at 0), c_N = (t_0 - c_0) g^-N
+    fe e, nn, c0v, gi, tn; ld(e, io.c0out + ((size_t)which * io.nnodes + k) * 8); ld(nn, io.consts + 24);
+    F::mul(c0v, e, nn);
+    st(dst, c0v);
+    ld(gi, io.consts + 32); F::sub(tn, t, c0v); F::mul(tn, tn, gi);
+    st(dst + (size_t)N * 8, tn);
+    return;
+  }
+  if (i < len) {
+    fe v = t;
+    if (i) { fe gm; ld(gm, io.GI + (size_t)i * 8); F::mul(v, v, gm); }
+    st(dst + (size_t)i * 8, v);
+  }
+}
+
+template <bool INV, int IO /* 0: buf -> buf; 1: the input is gathered from the coefficient arrays (fused k_load); 2: the output goes to the coefficient arrays (fused k_store) */>
 __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 total, u32 logN, u32 lo, u32 S,
-                                                  const u32* __restrict__ W, u32 log_half_max) {
+                                                  const u32* __restrict__ W, u32 log_half_max, TileIO io) {
   __shared__ u32 sm[8][1024];
   const u32 tid = threadIdx.x;
   const u32 TW = lo ? (1024u >> S) : 1u;            // lo > 0: TW tiles side by side; lo == 0: chunks of J inside 1024 contiguous
@@ -349,7 +402,7 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
     const u32 e = tid + 256u * q;
     const u64 g = gidx(e);
     fe v; F::set_zero(v);
-    if (g < total) ld(v, buf + g * 8);
+    if (g < total) { if (IO == 1) tile_load_coeff(v, io, g, logN); else ld(v, buf + g * 8); }
 #pragma unroll
     for (int l = 0; l < 8; l++) sm[l][e] = v.v[l];
   }
@@ -385,7 +438,7 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
       fe v;
 #pragma unroll
       for (int l = 0; l < 8; l++) v.v[l] = sm[l][e];
-      st(buf + g * 8, v);
+      if (IO == 2) tile_store_coeff(v, io, g, logN); else st(buf + g * 8, v);
     }
   }
 }

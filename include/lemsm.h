@@ -100,7 +100,9 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    own, 2 = let the accumulation consume them as passed in, 0 = choose by segment length and window
    count), "pyr_fuse" (0 = the narrow last steps of the bucket-reduction pyramid run in one launch, 1 = one launch per
    step: A/B knob), "ntt_tiled" (divisor witness: 0 = LDS-tiled transforms, up to 10 stages per launch; 2 = one launch per
-   stage: A/B knob), "dw_wrap" (divisor witness: 0 = levels whose longest part
+   stage: A/B knob), "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
+   input from the coefficient arrays and the last inverse pass scatters into them; 2 = separate load / store kernels:
+   A/B knob), "dw_wrap" (divisor witness: 0 = levels whose longest part
    has 2^k + 1 coefficients run on 2^k-point transforms, the folded top coefficient recovered from the value at x = 0;
    2 = always the next power of two: A/B knob), "ws_canary" (1 = debug: every sub-buffer of the MSM workspace is followed by a 256-byte guard that is
    filled before and verified after every window group; an overrun returns LEMSM_ERR_HIP naming the guard; the fuzz

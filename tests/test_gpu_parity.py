@@ -1054,6 +1054,27 @@ def test_divisor_witness_half_size_transforms_equal_full_size(ctx, n):
     assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
 
 
+@pytest.mark.parametrize("n", [2, 5, 16, 17, 300, 1024, 5000])
+def test_divisor_witness_fused_load_store_equals_separate_kernels(ctx, n):
+    """option dw_fuse: the first forward pass gathers from the coefficient arrays and the last inverse pass scatters into
+    them -- the same witness, coefficient for coefficient, as with k_load / k_store; lists with identities and repeats too"""
+    g = pyref.GRUMPKIN
+    q = cref.gen_points(g.cid, 1800 + n, 1)[0]
+    rows = ctx.gen_walk(g.cid, q, n).download(np.uint64).reshape(-1, 8).copy()
+    if n >= 5:
+        rows[1] = 0; rows[n - 2] = rows[0]                   # an identity and a repeated point: lengths off the regular pattern
+    res = []
+    try:
+        for mode in (0, 2):
+            ctx.set_option("dw_fuse", mode)
+            a, b, outp = ctx.divisor_witness(api.GRUMPKIN, rows, False, True)
+            res.append((a.copy(), b.copy(), outp.copy()))
+    finally:
+        ctx.set_option("dw_fuse", 0)
+    assert res[0][0].shape == res[1][0].shape and res[0][1].shape == res[1][1].shape
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
+
+
 def test_divisor_witness_10000_points(ctx):
     """the size of randpoints_witness_test (:650-662): 10 000 points (a walk k Q, so that the oracle needs no 10 000 scalar
     multiplications) and minus their sum; full coefficient comparison and the vanishing assertion on a sample"""
