@@ -270,7 +270,8 @@ int lemsm_divisor_witness_device(lemsm_ctx* ctx, int curve, const void* d_points
 int lemsm_divisor_witness_batch(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, const size_t* counts, size_t T,
                                 int require_zero_sum, int normalise, uint64_t* out_coeffs, size_t cap_coeffs,
                                 size_t* out_index, uint64_t* out_points_affine);
-/* Device time (ms) of the transform launches of the last divisor-witness call, their algorithmic bytes (every element
+/* Device time (ms) of the transform launches of the last divisor-witness call (with option dw_fuse at its default the
+   first forward and the last inverse pass of a level also gather from / scatter into the coefficient arrays), their algorithmic bytes (every element
    read once and written once per pass over HBM: 1 pass up to 2^10 elements, 2 up to 2^18, 3 beyond) and their butterfly
    count (one field multiplication each): the figures the HBM and VALU rooflines of the transforms are priced with. */
 int lemsm_divisor_last_ntt(const lemsm_ctx* ctx, double* ms, uint64_t* algorithmic_bytes, uint64_t* butterflies);
