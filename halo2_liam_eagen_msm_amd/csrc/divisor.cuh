@@ -154,34 +154,6 @@ __global__ __launch_bounds__(256) void k_merge_sum(const char* __restrict__ chil
   G::store(out_xyzz + (size_t)g * 128, acc);
 }
 
-// XYZZ -> affine, Montgomery's trick over KB points per thread (prefix products in scratch[k][thread]); identity -> (0,0)
-template <int KB>
-__global__ __launch_bounds__(256) void k_to_affine(const char* __restrict__ xyzz, u32 cnt, uint4* __restrict__ aff, char* __restrict__ scratch) {
-  const u32 t = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
-  const u64 j0 = (u64)t * KB;
-  if (j0 >= cnt) return;
-  const u32 m = (u32)min((u64)KB, (u64)cnt - j0);
-  fe acc; F::set_one(acc);
-  for (u32 k = 0; k < m; k++) {
-    G::pt p; G::load(p, xyzz + (j0 + k) * 128);
-    F::store(scratch + ((size_t)k * nthreads + t) * 32, acc);
-    if (!G::is_identity(p)) F::mul(acc, acc, p.zzz);
-  }
-  fe inv; F::inv(inv, acc);
-  for (u32 k = m; k-- > 0;) {
-    G::pt p; G::load(p, xyzz + (j0 + k) * 128);
-    uint4* o = aff + (j0 + k) * 4;
-    if (G::is_identity(p)) { o[0] = make_uint4(0, 0, 0, 0); o[1] = o[0]; o[2] = o[0]; o[3] = o[0]; continue; }
-    fe pref, izzz, iz, izz, x, y;
-    F::load(pref, scratch + ((size_t)k * nthreads + t) * 32);
-    F::mul(izzz, inv, pref);
-    F::mul(inv, inv, p.zzz);
-    F::mul(iz, p.zz, izzz); F::sqr(izz, iz);        // ZZ/ZZZ = 1/Z ; (1/Z)^2 = 1/ZZ
-    F::mul(x, p.x, izz); F::mul(y, p.y, izzz);
-    F::store(o, x); F::store(o + 2, y);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // leaves: the line of every pair (from_pair :328-331, from_point :319-322, empty :324-326)
 // ---------------------------------------------------------------------------------------------------------
