@@ -530,12 +530,54 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
   }
 }
 
-// pass B (nodes with divisions only): thread c of a node owns the slots i = c + q * stride (consecutive lanes on
-// consecutive elements in every trip) and shares ONE inversion among them (Montgomery's trick): prefix products of the
-// denominators forwards (parked in the R.a slots), inversion, then backwards the inverse of every denominator onto its
-// numerators.  Thread 0 also owns the node's extra slot.
-__global__ __launch_bounds__(256) void k_pw_inv(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
-                                                const u32* __restrict__ c0in, u32* __restrict__ c0out) {
+// pass B, three launches.  Thread c of a node owns the slots i = c + q * stride (consecutive lanes on consecutive elements
+// in every trip).  k_pw_prefix: prefix products of the thread's denominators forwards (parked in the R.a slots), the
+// product of all of them to roots[thread] (1 for threads of nodes without divisions).  k_pw_rootinv: the roots are
+// inverted by Montgomery's trick once more, RK of them per thread, so that a level pays one Fermat inversion per
+// RK * (slots per thread) elements instead of one per thread.  k_pw_apply: backwards over the same slots, the inverse of
+// every denominator onto its numerators.  Thread 0 of a node also owns the node's extra slot (wrap mode).
+__global__ __launch_bounds__(256) void k_pw_prefix(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
+                                                   const u32* __restrict__ c0in, u32* __restrict__ roots) {
+  const u32 N = 1u << logN;
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (u64)nnodes * stride) return;
+  const u32 k = (u32)(gid / stride), c = (u32)(gid - (u64)k * stride);
+  fe run; F::set_one(run);
+  if (plan[k].mode == MODE_DIVIDE) {
+    const size_t per = (size_t)nnodes << logN;
+    u32* sRa = buf + (2 * per + ((size_t)k << logN)) * 8; const u32* sRb = sRa + per * 8;
+    for (u32 i = c; i < N; i += stride) {
+      fe den; ld(den, sRb + (size_t)i * 8);
+      st(sRa + (size_t)i * 8, run);                                        // prefix product before this element
+      F::mul(run, run, den);
+    }
+    if (c0in != nullptr && c == 0) { fe eden; ld(eden, c0in + ((size_t)3 * nnodes + k) * 8); F::mul(run, run, eden); }   // (its prefix is the product of the thread's regular slots: recomputed in k_pw_apply)
+  }
+  st(roots + gid * 8, run);
+}
+
+static const u32 DW_RK = 32;     // roots per thread of k_pw_rootinv
+__global__ __launch_bounds__(256) void k_pw_rootinv(u32* __restrict__ roots, u32* __restrict__ rpre /* scratch, as long as roots */, u64 count) {
+  const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 r0 = t * DW_RK;
+  if (r0 >= count) return;
+  const u32 m = (u32)min((u64)DW_RK, count - r0);
+  fe run; F::set_one(run);
+  for (u32 j = 0; j < m; j++) {
+    fe v; ld(v, roots + (r0 + j) * 8);
+    st(rpre + (r0 + j) * 8, run);
+    F::mul(run, run, v);
+  }
+  fe inv; inv_fast(inv, run);
+  for (u32 j = m; j-- > 0;) {
+    fe v, pj, o; ld(v, roots + (r0 + j) * 8); ld(pj, rpre + (r0 + j) * 8);
+    F::mul(o, inv, pj); F::mul(inv, inv, v);
+    st(roots + (r0 + j) * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pw_apply(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
+                                                  const u32* __restrict__ c0in, u32* __restrict__ c0out, const u32* __restrict__ rootinv) {
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (u64)nnodes * stride) return;
@@ -543,41 +585,25 @@ __global__ __launch_bounds__(256) void k_pw_inv(u32* __restrict__ buf, const Pla
   if (plan[k].mode != MODE_DIVIDE) return;
   const size_t per = (size_t)nnodes << logN;
   u32* sLa = buf + (((size_t)k << logN)) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
-  fe run; F::set_one(run);
-  {
-    fe nden;                                                             // the next slot's denominator is requested before this slot's product
-    if (c < N) ld(nden, sRb + (size_t)c * 8);
-    for (u32 i = c; i < N; i += stride) {
-      fe den = nden;
-      if (i + stride < N) ld(nden, sRb + (size_t)(i + stride) * 8);
-      st(sRa + (size_t)i * 8, run);                                      // prefix product before this element
-      F::mul(run, run, den);
-    }
-  }
-  const bool extra = c0in != nullptr && c == 0;
-  fe epref, eden;
-  if (extra) { ld(eden, c0in + ((size_t)3 * nnodes + k) * 8); epref = run; F::mul(run, run, eden); }
-  fe inv; inv_fast(inv, run);
-  if (extra) {
-    fe di, A, Bv; F::mul(di, inv, epref); F::mul(inv, inv, eden);
+  fe inv; ld(inv, rootinv + gid * 8);
+  const u32 cnt = c < N ? (N - c + stride - 1) / stride : 0u;      // slots of this thread
+  if (c0in != nullptr && c == 0) {
+    // the extra slot came last in the product: its prefix = product of the regular slots = prefix of the last slot * its denominator
+    fe epref, eden, di, A, Bv;
+    if (cnt) { fe lp, ld_; const u32 il = c + (cnt - 1) * stride; ld(lp, sRa + (size_t)il * 8); ld(ld_, sRb + (size_t)il * 8); F::mul(epref, lp, ld_); }
+    else F::set_one(epref);
+    ld(eden, c0in + ((size_t)3 * nnodes + k) * 8);
+    F::mul(di, inv, epref); F::mul(inv, inv, eden);
     ld(A, c0out + ((size_t)0 * nnodes + k) * 8); ld(Bv, c0out + ((size_t)1 * nnodes + k) * 8);
     F::mul(A, A, di); F::mul(Bv, Bv, di);
     st(c0out + ((size_t)0 * nnodes + k) * 8, A); st(c0out + ((size_t)1 * nnodes + k) * 8, Bv);
   }
-  const u32 cnt = c < N ? (N - c + stride - 1) / stride : 0u;      // slots of this thread
-  fe npref, nden, nA, nB;                                // operands of the next slot down, requested one slot ahead
-  if (cnt) {
-    const u32 i = c + (cnt - 1) * stride;
-    ld(npref, sRa + (size_t)i * 8); ld(nden, sRb + (size_t)i * 8); ld(nA, sLa + (size_t)i * 8); ld(nB, sLb + (size_t)i * 8);
-  }
   for (u32 q = cnt; q-- > 0;) {
     const u32 i = c + q * stride;
-    fe pref = npref, den = nden, A = nA, Bv = nB, di;
-    if (q) {
-      const u32 j = i - stride;
-      ld(npref, sRa + (size_t)j * 8); ld(nden, sRb + (size_t)j * 8); ld(nA, sLa + (size_t)j * 8); ld(nB, sLb + (size_t)j * 8);
-    }
+    fe pref, den, di, A, Bv;
+    ld(pref, sRa + (size_t)i * 8); ld(den, sRb + (size_t)i * 8);
     F::mul(di, inv, pref); F::mul(inv, inv, den);
+    ld(A, sLa + (size_t)i * 8); ld(Bv, sLb + (size_t)i * 8);
     F::mul(A, A, di); F::mul(Bv, Bv, di);
     st(sLa + (size_t)i * 8, A); st(sLb + (size_t)i * 8, Bv);
   }

@@ -100,7 +100,8 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    own, 2 = let the accumulation consume them as passed in, 0 = choose by segment length and window
    count), "pyr_fuse" (0 = the narrow last steps of the bucket-reduction pyramid run in one launch, 1 = one launch per
    step: A/B knob), "ntt_tiled" (divisor witness: 0 = LDS-tiled transforms, up to 10 stages per launch; 2 = one launch per
-   stage: A/B knob), "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
+   stage: A/B knob), "dw_kb" (divisor witness: slots per thread of the batched-inversion kernels, 8..64; 0 = auto),
+   "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
    input from the coefficient arrays and the last inverse pass scatters into them; 2 = separate load / store kernels:
    A/B knob), "dw_wrap" (divisor witness: 0 = levels whose longest part
    has 2^k + 1 coefficients run on 2^k-point transforms, the folded top coefficient recovered from the value at x = 0;
