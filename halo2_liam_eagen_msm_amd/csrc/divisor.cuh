@@ -556,12 +556,12 @@ __global__ __launch_bounds__(256) void k_pw_prefix(u32* __restrict__ buf, const 
   st(roots + gid * 8, run);
 }
 
-static const u32 DW_RK = 32;     // roots per thread of k_pw_rootinv
-__global__ __launch_bounds__(256) void k_pw_rootinv(u32* __restrict__ roots, u32* __restrict__ rpre /* scratch, as long as roots */, u64 count) {
+static const u32 DW_RK = 32;     // most roots per thread of k_pw_rootinv (fewer when a level has few roots: a short level is latency, not work)
+__global__ __launch_bounds__(256) void k_pw_rootinv(u32* __restrict__ roots, u32* __restrict__ rpre /* scratch, as long as roots */, u64 count, u32 rk /* roots per thread */) {
   const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
-  const u64 r0 = t * DW_RK;
+  const u64 r0 = t * rk;
   if (r0 >= count) return;
-  const u32 m = (u32)min((u64)DW_RK, count - r0);
+  const u32 m = (u32)min((u64)rk, count - r0);
   fe run; F::set_one(run);
   for (u32 j = 0; j < m; j++) {
     fe v; ld(v, roots + (r0 + j) * 8);
