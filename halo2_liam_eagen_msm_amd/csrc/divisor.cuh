@@ -474,17 +474,22 @@ __device__ __forceinline__ void pw_numerators(fe& A, fe& Bv, fe& den, bool divid
                                               const fe& La, const fe& Lb, const fe& Ra, const fe& Rb,
                                               const fe& c0, const fe& c1, const fe& d0, const fe& lX, const fe& lZZ, const fe& rX, const fe& rZZ, const fe& ninv) {
   fe t, u;
+  // (p + y q)(r + y w) with y^2 = s, by three products and one more for s (Karatsuba): p r + s q w,  (p + q)(r + w) - p r - q w
+  auto rfmul = [&](fe& oa, fe& ob, const fe& pp, const fe& qq, const fe& rr, const fe& ww) {
+    fe m1, m2, m3, e, f;
+    F::mul(m1, pp, rr); F::mul(m2, qq, ww);
+    F::add(e, pp, qq); F::add(f, rr, ww); F::mul(m3, e, f);
+    F::sub(m3, m3, m1); F::sub(ob, m3, m2);
+    F::mul(e, m2, s); F::add(oa, m1, e);
+  };
   if (divide) {
     fe l, tA, tB;
     F::mul(l, c1, x); F::add(l, l, c0);                               // c0 + c1 x
-    F::mul(tA, Ra, l); F::mul(t, Rb, d0); F::mul(t, t, s); F::add(tA, tA, t);     // R.a l + R.b d0 s
-    F::mul(tB, Ra, d0); F::mul(t, Rb, l); F::add(tB, tB, t);                        // R.a d0 + R.b l
-    F::mul(A, La, tA); F::mul(t, Lb, tB); F::mul(t, t, s); F::add(A, A, t);
-    F::mul(Bv, La, tB); F::mul(t, Lb, tA); F::add(Bv, Bv, t);
+    rfmul(tA, tB, Ra, Rb, l, d0);                                     // R.w * line:  R.a l + s R.b d0,  R.a d0 + R.b l
+    rfmul(A, Bv, La, Lb, tA, tB);                                     // L.w * (..)
     F::mul(t, lZZ, x); F::sub(t, t, lX); F::mul(u, rZZ, x); F::sub(u, u, rX); F::mul(den, t, u);   // (ZZ_L x - X_L)(ZZ_R x - X_R)
   } else {
-    F::mul(A, La, Ra); F::mul(t, Lb, Rb); F::mul(t, t, s); F::add(A, A, t);
-    F::mul(Bv, La, Rb); F::mul(t, Lb, Ra); F::add(Bv, Bv, t);
+    rfmul(A, Bv, La, Lb, Ra, Rb);
     F::mul(A, A, ninv); F::mul(Bv, Bv, ninv);                          // 1/N of the inverse transform
     F::set_one(den);
   }
