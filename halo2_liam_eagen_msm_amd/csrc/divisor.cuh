@@ -379,9 +379,28 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
     for (int l = 0; l < 8; l++) sm[l][e] = v.v[l];
   }
   __syncthreads();
-  for (u32 st_ = 0; st_ < S; st_++) {
-    const u32 ls = INV ? st_ : (S - 1 - st_);        // local span 2^ls (in tile positions j)
+  // twiddle of the butterfly whose lower element sits at tile position j (sub-tile tw), local span 2^ls
+  auto tw_of = [&](fe& w, u32 j, u32 tw, u32 ls) {
     const u32 logm = lo + ls;                        // global span
+    const u32 r = lo == 0 ? (j & ((1u << ls) - 1)) : (((j & ((1u << ls) - 1)) << lo) + Lfull0 + tw);   // global index of the element mod 2^logm
+    twiddle(w, W, 1u << log_half_max, r << (log_half_max - logm), INV);
+  };
+  auto lds_get = [&](fe& v, u32 e) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) v.v[l] = sm[l][e];
+  };
+  auto lds_put = [&](u32 e, const fe& v) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) sm[l][e] = v.v[l];
+  };
+  auto bfly = [&](fe& u, fe& v, const fe& w) {
+    fe x, y;
+    if (!INV) { F::add(x, u, v); F::sub(y, u, v); F::mul(y, y, w); }
+    else { fe t; F::mul(t, v, w); F::add(x, u, t); F::sub(y, u, t); }
+    u = x; v = y;
+  };
+  // one stage: two butterflies per thread, through LDS
+  auto single = [&](u32 ls) {
 #pragma unroll
     for (u32 q = 0; q < 2; q++) {
       const u32 bb = tid + 256u * q;                 // butterfly 0..511
@@ -389,18 +408,36 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
       const u32 tw = bb & (TW - 1), p = bb >> logTW;                 // p in [0, 512 / TW): over (chunk, j-pairs)
       const u32 j0 = ((p >> ls) << (ls + 1)) + (p & ((1u << ls) - 1));   // position (chunk bits included for lo == 0)
       const u32 e0 = (j0 << logTW) + tw, e1 = e0 + ((1u << ls) << logTW);
-      // r = global index of e0 mod 2^logm
-      const u32 r = lo == 0 ? (j0 & ((1u << ls) - 1)) : (((j0 & ((1u << ls) - 1)) << lo) + Lfull0 + tw);
-      fe w; twiddle(w, W, 1u << log_half_max, r << (log_half_max - logm), INV);
-      fe u, v, x, y;
-#pragma unroll
-      for (int l = 0; l < 8; l++) { u.v[l] = sm[l][e0]; v.v[l] = sm[l][e1]; }
-      if (!INV) { F::add(x, u, v); F::sub(y, u, v); F::mul(y, y, w); }
-      else { F::mul(v, v, w); F::add(x, u, v); F::sub(y, u, v); }
-#pragma unroll
-      for (int l = 0; l < 8; l++) { sm[l][e0] = x.v[l]; sm[l][e1] = y.v[l]; }
+      fe w; tw_of(w, j0, tw, ls);
+      fe u, v; lds_get(u, e0); lds_get(v, e1);
+      bfly(u, v, w);
+      lds_put(e0, u); lds_put(e1, v);
     }
     __syncthreads();
+  };
+  // two stages (spans 2^b and 2^(b+1)) on four elements held in registers: half the LDS traffic and barriers of two
+  // single stages (the four products are the same: a prime field has no free multiplication by the fourth root of unity)
+  auto pair = [&](u32 b) {
+    const u32 tw = tid & (TW - 1), p = tid >> logTW;               // p in [0, 256 / TW)
+    const u32 j00 = ((p >> b) << (b + 2)) | (p & ((1u << b) - 1));
+    const u32 j01 = j00 + (1u << b), j10 = j00 + (2u << b), j11 = j00 + (3u << b);
+    const u32 e0 = (j00 << logTW) + tw, e1 = (j01 << logTW) + tw, e2 = (j10 << logTW) + tw, e3 = (j11 << logTW) + tw;
+    fe x0, x1, x2, x3, wl, wh0, wh1;
+    lds_get(x0, e0); lds_get(x1, e1); lds_get(x2, e2); lds_get(x3, e3);
+    tw_of(wl, j00, tw, b); tw_of(wh0, j00, tw, b + 1); tw_of(wh1, j01, tw, b + 1);
+    if (!INV) { bfly(x0, x2, wh0); bfly(x1, x3, wh1); bfly(x0, x1, wl); bfly(x2, x3, wl); }
+    else { bfly(x0, x1, wl); bfly(x2, x3, wl); bfly(x0, x2, wh0); bfly(x1, x3, wh1); }
+    lds_put(e0, x0); lds_put(e1, x1); lds_put(e2, x2); lds_put(e3, x3);
+    __syncthreads();
+  };
+  if (!INV) {            // spans from 2^(S-1) down
+    int ls = (int)S - 1;
+    for (; ls >= 1; ls -= 2) pair((u32)ls - 1);
+    if (ls == 0) single(0);
+  } else {               // spans from 2^0 up
+    u32 ls = 0;
+    for (; ls + 1 < S; ls += 2) pair(ls);
+    if (ls < S) single(ls);
   }
 #pragma unroll
   for (u32 q = 0; q < 4; q++) {
