@@ -100,10 +100,6 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     logn = args.logn if args.logn is not None else (24 if args.workload == "msm" else (18 if args.workload == "lhs_witness" else 20))
     n = 1 << logn
-    if args.workload == "lhs_witness":
-        if world != 1:
-            raise SystemExit("--workload lhs_witness is a one-GPU line (the d trees of a call would shard by digit position with no exchange; not built)")
-        return bench_lhs_witness(args, n, logn)
 
     import torch
     import torch.distributed as dist
@@ -124,6 +120,12 @@ def main():
     from halo2_liam_eagen_msm_amd import Context
     from halo2_liam_eagen_msm_amd import dist as ldist
     ctx = Context(dev_index)
+    if args.workload == "lhs_witness":
+        bench_lhs_witness(args, ctx, n, logn, world, rank, dist, torch, dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     curve = args.curve
     cid = {"bn254_g1": 0, "grumpkin": 1}[curve]
     order = ORDER[curve]
@@ -264,15 +266,15 @@ def main():
 BUTTERFLY_PEAK = 115e9   # ~1200 issue cycles per wave-butterfly (strict 8x32-bit Montgomery product + add + sub) on 1024 SIMDs at 2.1 GHz
 
 
-def bench_lhs_witness(args, n, logn):
+def bench_lhs_witness(args, ctx, n, logn, world, rank, dist, torch, red_dev):
     """compute_lhs_witness in full (src/argument_witness_calc.rs:87-136: the carry AND the d divisor witnesses), Grumpkin,
     scalars / affine points resident in HBM and the coefficients left in HBM (lemsm_lhs_witness_device).  One JSON line of
     the same shape as the MSM workloads; `roofline` prices the transform launches of the merge forest (device time from
-    HIP events inside the library, algorithmic bytes = one read + one write of every 32-byte element per pass over HBM)."""
-    import torch
-    from halo2_liam_eagen_msm_amd import Context, DeviceBuffer, num_digits
-    torch.cuda.set_device(0)
-    ctx = Context(0)
+    HIP events inside the library, algorithmic bytes = one read + one write of every 32-byte element per pass over HBM).
+    N > 1: the d merge trees are independent, so rank r computes the functions of its share of the digit positions
+    (dist.window_range) on replicated inputs -- no exchange; every rank runs the MSM core for the carries."""
+    from halo2_liam_eagen_msm_amd import DeviceBuffer, num_digits
+    from halo2_liam_eagen_msm_amd import dist as ldist
     cid, curve = 1, "grumpkin"
     order = ORDER[curve]; fp = ORDER["bn254_g1"]
     scalars = gen_scalars(n, math.isqrt(order), 0x5EED1000 + logn)
@@ -287,13 +289,19 @@ def bench_lhs_witness(args, n, logn):
         ctx.set_option(name, int(val))
     d = num_digits(cid, args.base)
     out = DeviceBuffer(ctx, 2 * d * (n + args.base + 3) * 32)
+    f_range = ldist.window_range(d, world, rank) if world > 1 else None
 
     def step():
-        return ctx.lhs_witness_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True, out)
+        return ctx.lhs_witness_device(cid, d_scalars.ptr, d_points.ptr, n, args.base, True, out, f_range)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     ntt_ms = 0.0; ntt_bytes = 0; ntt_bf = 0; phases = np.zeros(4)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -301,8 +309,14 @@ def bench_lhs_witness(args, n, logn):
         ms, by, bf = ctx.divisor_last_ntt()
         ntt_ms += ms; ntt_bytes += by; ntt_bf += bf
         phases += np.array(ctx.lhs_witness_last_phases())
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
     ms_per_step = elapsed / args.steps * 1e3
     achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
     coeffs = int(index[:, 1].sum() + index[:, 3].sum())
@@ -314,15 +328,16 @@ def bench_lhs_witness(args, n, logn):
                                      "frac": round(ntt_bf / (ntt_ms * 1e-3) / BUTTERFLY_PEAK, 4) if ntt_ms > 0 else 0.0,
                                      "model": "model-derived peak: ~1200 issue cycles per wave-butterfly x 1024 SIMDs at 2.1 GHz"},
                 "phases_ms": {k: round(float(v) / args.steps, 2) for k, v in zip(("msm_core", "point_lists", "merge_forest", "coefficient_copy"), phases)}}
-    checks = verify_lhs_witness(ctx, cid, scalars, q, d_points, n, args.base, carry, index, out)
+    checks = verify_lhs_witness(ctx, cid, scalars, q, d_points, n, args.base, carry, index, out, f_range)
     res = {"metric": "Grumpkin compute_lhs_witness scalar-point-pairs/s (carry + %d divisor witnesses)" % d, "value": round(n * args.steps / elapsed, 1), "unit": "pairs/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
            "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery integers)", "data": "synthetic",
            "config": {"workload": "grumpkin compute_lhs_witness in full, 2^%d points, negabase B=%d, half-width scalars" % (logn, args.base), "n": n, "curve": curve,
                       "coefficients_per_step": coeffs, "baseline_config": "SURVEY section 8 row f2 (the second return value of compute_lhs_witness); no BASELINE.json config names it",
-                      "io": "scalars and affine points resident in HBM, coefficients left in HBM (lemsm_lhs_witness_device)"},
+                      "io": "scalars and affine points resident in HBM, coefficients left in HBM (lemsm_lhs_witness_device)",
+                      "sharding": "single GPU" if world == 1 else "digit positions x%d (independent merge trees, no exchange; rank 0's figures in roofline)" % world},
            "roofline": roofline}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_lhs_witness(ctx, cid, scalars, d_points, args)
         checks.append("sample vs oracle (every coefficient of every function)")
     if args.option:
@@ -332,7 +347,7 @@ def bench_lhs_witness(args, n, logn):
     print(json.dumps(res), flush=True)
 
 
-def verify_lhs_witness(ctx, cid, scalars, q, d_points, n, base, carry, index, out):
+def verify_lhs_witness(ctx, cid, scalars, q, d_points, n, base, carry, index, out, f_range=None):
     """Checker leg for the timed compute_lhs_witness result: the carry against the closed form of the synthetic input, the
     shape of every function, and the property the reference's own test asserts (randpoints_witness_test :661): a function
     vanishes on the points of its list -- checked for one digit position on a multiple d_j P_j picked from the digits the
@@ -344,7 +359,8 @@ def verify_lhs_witness(ctx, cid, scalars, q, d_points, n, base, carry, index, ou
     checks = ["timed carry vs walk identity"]
     g = pyref.GRUMPKIN; p = g.fp
     d = index.shape[0]
-    for f in range(d):
+    mine = range(d) if f_range is None else range(f_range[0], f_range[1])
+    for f in mine:
         oa, la, ob, lb = (int(v) for v in index[f])
         if not (la + lb >= 1 and la + lb <= 2 * (n + base + 3)):
             raise SystemExit("function %d has an impossible shape (%d, %d)" % (f, la, lb))
@@ -352,7 +368,7 @@ def verify_lhs_witness(ctx, cid, scalars, q, d_points, n, base, carry, index, ou
     qa = g.raw_to_affine(q.tobytes())
     digs = {j: pyref.negbase_digits_padded(int.from_bytes(scalars[j].tobytes(), "little"), base, d) for j in (0, 1, n // 2, n - 1)}   # LSB first
     done = 0
-    for pos in range(d):
+    for pos in mine:
         js = [j for j, dg in digs.items() if dg[pos]]
         if not js or done >= 2:
             continue

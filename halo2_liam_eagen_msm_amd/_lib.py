@@ -55,7 +55,7 @@ SYMBOLS = [
     "lemsm_bases_upload", "lemsm_bases_free", "lemsm_bases_device_ptr", "lemsm_msm_with_bases",
     "lemsm_debug_msm_sharded_sim", "lemsm_debug_lhs_sharded_sim",
     "lemsm_prepare_scalar_witness_batch", "lemsm_table_entries",
-    "lemsm_divisor_witness", "lemsm_divisor_witness_device", "lemsm_divisor_witness_batch", "lemsm_divisor_last_ntt", "lemsm_lhs_witness", "lemsm_lhs_witness_device", "lemsm_lhs_witness_last_phases", "lemsm_debug_ntt",
+    "lemsm_divisor_witness", "lemsm_divisor_witness_device", "lemsm_divisor_witness_batch", "lemsm_divisor_last_ntt", "lemsm_lhs_witness", "lemsm_lhs_witness_device", "lemsm_lhs_witness_device_range", "lemsm_lhs_witness_last_phases", "lemsm_debug_ntt",
     "lemsm_to_curve_x", "lemsm_y_from_x", "lemsm_slope",
 ]
 
@@ -154,6 +154,7 @@ def load() -> ctypes.CDLL:
         "lemsm_divisor_last_ntt": (i, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
         "lemsm_lhs_witness": (i, [vp, i, u8p, u64p, sz, ctypes.c_uint8, u64p, u64p, sz, szp, i, szp]),
         "lemsm_lhs_witness_device": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, u64p, vp, sz, szp, i, szp]),
+        "lemsm_lhs_witness_device_range": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint32, u64p, vp, sz, szp, i, szp]),
         "lemsm_debug_ntt": (i, [vp, u64p, u64p, sz, ctypes.c_uint32, i]),
         "lemsm_to_curve_x": (i, [i, u64p, u64p]),
         "lemsm_y_from_x": (i, [i, u64p, u64p, ctypes.POINTER(i)]),

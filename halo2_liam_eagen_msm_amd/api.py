@@ -391,10 +391,11 @@ class Context:
         return carry, fns
 
     def lhs_witness_device(self, curve, d_scalars: int, d_points_affine: int, n: int, base: int, normalise: bool = True,
-                           out: Optional[DeviceBuffer] = None):
+                           out: Optional[DeviceBuffer] = None, f_range: Optional[Tuple[int, int]] = None):
         """compute_lhs_witness in full with scalars / affine points resident in HBM and the coefficients left there:
         (carry, index[d, 4] = {offset_a, len_a, offset_b, len_b} in 32-byte elements, DeviceBuffer of the coefficients).
-        `out`: a buffer of at least 2 d (n + base + 3) elements to reuse across calls."""
+        `out`: a buffer of at least 2 d (n + base + 3) elements to reuse across calls.  `f_range` = (begin, end): only
+        those functions (a rank's share; the others' index rows read length 0)."""
         cid = _curve_id(curve)
         if not (3 <= base <= 255):
             raise BadBase(_lib.LEMSM_ERR_BAD_BASE, "base must be in 3..=255")
@@ -406,8 +407,12 @@ class Context:
         index = np.zeros((d, 4), np.uintp)
         carry = np.zeros(12, np.uint64)
         bad = ctypes.c_size_t(0)
-        rc = self.lib.lemsm_lhs_witness_device(self.h, cid, d_scalars, d_points_affine, n, base, _ptr(carry), out.ptr, cap,
-                                               index.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), int(normalise), ctypes.byref(bad))
+        if f_range is None:
+            rc = self.lib.lemsm_lhs_witness_device(self.h, cid, d_scalars, d_points_affine, n, base, _ptr(carry), out.ptr, cap,
+                                                   index.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), int(normalise), ctypes.byref(bad))
+        else:
+            rc = self.lib.lemsm_lhs_witness_device_range(self.h, cid, d_scalars, d_points_affine, n, base, int(f_range[0]), int(f_range[1]), _ptr(carry),
+                                                         out.ptr, cap, index.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), int(normalise), ctypes.byref(bad))
         self._check(rc, bad.value)
         return carry, index, out
 

@@ -291,6 +291,12 @@ int lemsm_lhs_witness(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const u
 int lemsm_lhs_witness_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine, size_t n,
                              uint8_t base, uint64_t out_carry[12], void* d_out_coeffs, size_t cap_coeffs, size_t* out_index,
                              int normalise, size_t* bad_index);
+/* A rank's share of it: only the functions [f_begin, f_end) of the d of the call are computed (out_index rows of the
+   others read length 0).  The d merge trees are independent, so a node shards compute_lhs_witness by digit position with
+   no exchange (halo2_liam_eagen_msm_amd.dist.window_range gives the split); every rank runs the MSM core for the carries. */
+int lemsm_lhs_witness_device_range(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points_affine, size_t n,
+                                   uint8_t base, uint32_t f_begin, uint32_t f_end, uint64_t out_carry[12], void* d_out_coeffs,
+                                   size_t cap_coeffs, size_t* out_index, int normalise, size_t* bad_index);
 /* Host-clock milliseconds of the four phases of the last lemsm_lhs_witness call (each ends on a stream synchronise):
    [0] the MSM core (upload of scalars and points, digits, buckets, carries), [1] the table of multiples and the d point
    lists, [2] the merge forest (every field operation of the divisor witnesses), [3] the download of the coefficients

@@ -1206,6 +1206,38 @@ def test_lhs_witness_device_entry_equals_host_entry(ctx, base, n):
         assert (flat[oa: oa + la] == a).all() and (flat[ob: ob + lb] == b).all(), f
 
 
+def test_lhs_witness_function_ranges_are_the_full_call_in_pieces(ctx):
+    """lemsm_lhs_witness_device_range: the d merge trees are independent -- three ranks' shares (dist.window_range), an empty
+    share among them, put together are the full call: same carry from every share, the same coefficients function by function"""
+    from halo2_liam_eagen_msm_amd import dist as ldist
+    g = pyref.GRUMPKIN
+    n, base = 200, 5
+    rng = pyref.SplitMix64(2700)
+    sc = pyref.gen_scalars_half(rng, n, g.order)
+    scb = np.frombuffer(pyref.scalars_to_bytes(sc), np.uint8).reshape(-1, 32)
+    q = cref.gen_points(g.cid, 2701, 1)[0]
+    dp = ctx.gen_walk(g.cid, q, n)
+    ds = ctx.to_device(scb)
+    carry, index, out = ctx.lhs_witness_device(g.cid, ds.ptr, dp.ptr, n, base, True)
+    full = out.download(np.uint64).reshape(-1, 4)
+    d = index.shape[0]
+    seen = 0
+    for world, rank in ((3, 0), (3, 1), (3, 2), (d + 5, 1), (d + 5, d + 4)):
+        f0, f1 = ldist.window_range(d, world, rank)
+        c2, ix2, out2 = ctx.lhs_witness_device(g.cid, ds.ptr, dp.ptr, n, base, True, None, (f0, f1))
+        assert canon(g, c2) == canon(g, carry)
+        part = out2.download(np.uint64).reshape(-1, 4)
+        for f in range(d):
+            oa, la, ob, lb = (int(v) for v in index[f]); pa, qa, pb, qb = (int(v) for v in ix2[f])
+            if f0 <= f < f1:
+                assert (qa, qb) == (la, lb), f
+                assert (part[pa: pa + qa] == full[oa: oa + la]).all() and (part[pb: pb + qb] == full[ob: ob + lb]).all(), f
+                seen += world == 3
+            else:
+                assert (qa, qb) == (0, 0), f
+    assert seen == d
+
+
 def test_divisor_witness_2p20_vanishes_on_its_points(ctx):
     """full size (the point count of configs[1]'s per-digit lists): 2^20 walk points k Q and minus their sum
     (n (n + 1) / 2 Q); the size-independent property the reference asserts (randpoints_witness_test :661): the
