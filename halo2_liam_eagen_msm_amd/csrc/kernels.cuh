@@ -508,9 +508,11 @@ __global__ __launch_bounds__(256) void k_scatter2(GroupPlan pl, const u32* __res
 // global atomics, no tile table, and the bucket starts fall out of the block's own scan.  Bins over pl.bin_cap entries
 // (skewed scalars) are left to the tiled kernels above, whose tile table then lists those bins only.
 static const u32 BIN_CAP = 36864;    // 144 KiB of the CU's 160 KiB LDS
+static const u32 BIN_CAP_SMALL = 8192;   // the variant for short bins (below 2^22 points): 32 KiB, four blocks per CU, 8 entries per thread instead of 36 mostly idle slots
+template <u32 CAP>
 __global__ __launch_bounds__(1024) void k_binsort(GroupPlan pl, const u32* __restrict__ entries, const u32* __restrict__ bin_start,
                                                   u32* __restrict__ sorted, u32* __restrict__ bucket_start) {
-  __shared__ u32 stage[BIN_CAP];
+  __shared__ u32 stage[CAP];
   __shared__ u32 hist[256];
   __shared__ u32 lstart[256];
   __shared__ u32 wsum[4];
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_binsort(GroupPlan pl, const u32* __res
   const u32 nl = 1u << pl.LB, lmask = nl - 1u;
   if (tid < 256) hist[tid] = 0;
   __syncthreads();
-  constexpr int PER = BIN_CAP / 1024;
+  constexpr int PER = CAP / 1024;
   u32 e[PER], rk[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) { u32 i = off + tid + 1024u * k; e[k] = i < end ? entries[i] : 0u; }

@@ -415,6 +415,8 @@ GroupPlan make_group_plan(const lemsm_ctx* ctx, u32 n, u32 c, u32 nb, u32 W, u32
   g.T2 = T2;
   g.max_tiles = (u32)(Mmax / T2) + g.nbins + 1;
   g.bin_cap = ctx->opt_binsort == 2 ? 0u : (ctx->opt_binsort > 2 ? std::min((u32)ctx->opt_binsort, (u32)BIN_CAP) : (u32)BIN_CAP);
+  // short bins (uniform digits put n / BW entries in each): the 32-KiB variant of k_binsort, with room for 1.5x the mean
+  if (g.bin_cap == BIN_CAP && g.BW && (u64)n * 3 / 2 / g.BW <= BIN_CAP_SMALL) g.bin_cap = BIN_CAP_SMALL;
   u32 L1;
   if (ctx->opt_chunk > 0) L1 = (u32)ctx->opt_chunk;
   else {
@@ -538,7 +540,8 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   const u32* d_sorted = w.entries;
   const u32* d_bstart = w.bin_start;
   if (pl.LB > 0) {
-    if (pl.bin_cap) hipLaunchKernelGGL(k_binsort, dim3(pl.nbins), dim3(1024), 0, st, pl, w.entries, w.bin_start, w.sorted, w.bucket_start);
+    if (pl.bin_cap && pl.bin_cap <= BIN_CAP_SMALL) hipLaunchKernelGGL((k_binsort<BIN_CAP_SMALL>), dim3(pl.nbins), dim3(1024), 0, st, pl, w.entries, w.bin_start, w.sorted, w.bucket_start);
+    else if (pl.bin_cap) hipLaunchKernelGGL((k_binsort<BIN_CAP>), dim3(pl.nbins), dim3(1024), 0, st, pl, w.entries, w.bin_start, w.sorted, w.bucket_start);
     hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
     const u32 g2 = pl.bin_cap ? std::min(pl.max_tiles, 2048u) : pl.max_tiles;   // with k_binsort the tiled kernels see the oversize bins only: a small grid walks the (usually empty) tile table
     hipLaunchKernelGGL(k_count2, dim3(g2), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
