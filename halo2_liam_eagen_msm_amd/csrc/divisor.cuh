@@ -31,6 +31,7 @@
 #pragma once
 #include "xyzz.cuh"
 #include "field29.cuh"
+#include "inv29.cuh"
 
 namespace lemsm {
 namespace dw {
@@ -60,29 +61,8 @@ __device__ __forceinline__ void st(u32* p, const fe& a) {
 }
 __device__ __forceinline__ bool aff_id(const fe& x, const fe& y) { return F::is_zero(x) && F::is_zero(y); }
 
-// a^-1 (Montgomery form in, Montgomery form out) by Fermat in the lazy 29-bit field: 254 squarings of ~190 instructions
-// and ~130 products of ~225 instead of 381 products of ~370 (field32's inv) -- one inversion's latency is the floor of
-// every level's pointwise kernel.
-__device__ __noinline__ void inv_fast(fe& r, const fe& a) {
-  typedef Field29<Fr29Params> F29;
-  F29::fe x, acc;
-  F29::unpack(x, a.v); F29::from_abi(x, x);            // a 2^256 -> a 2^261 (the lazy field's domain)
-  F29::set_one(acc);
-  u32 e[8]; u32 bw = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) e[i] = __builtin_subc(FrParams::N[i], i == 0 ? 2u : 0u, bw, &bw);   // r - 2
-  for (int w = 0; w < 8; w++) {
-    u32 bits = e[w];
-    for (int j = 0; j < 32; j++) {
-      if (bits & 1u) F29::mul(acc, acc, x);
-      F29::sqr(x, x);
-      bits >>= 1;
-    }
-  }
-  F29::div32(acc, acc);                                  // back to the 2^256 domain
-  F29::canon(acc);
-  F29::pack(r.v, acc);
-}
+// a^-1 by Fermat in the lazy 29-bit field (inv29.cuh)
+__device__ __forceinline__ void inv_fast(fe& r, const fe& a) { inv_lazy<FrParams, Fr29Params>(r, a); }
 
 // line through two affine, non-identity points P = (x1,y1), Q = (x2,y2): lx x + ly y + lz with
 // lx = y1 - y2, ly = x2 - x1, lz = x1 y2 - y1 x2  (linefunc :290-292 with z = 1); all zero iff P == Q.

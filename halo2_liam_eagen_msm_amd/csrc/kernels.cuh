@@ -14,6 +14,7 @@
 //   halo2 best_multiexp (third party) bucket accumulation       -> k_pip_digits/PipDec + same kernels
 #pragma once
 #include "kernels_ec.cuh"
+#include "inv29.cuh"
 
 namespace lemsm {
 
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256) void k_jac_to_affine(const uint4* __restrict__
     F::store(scratch + ((size_t)k * nthreads + t) * 32, acc);
     if (!F::is_zero(z)) F::mul(acc, acc, z);
   }
-  fe inv; F::inv(inv, acc);
+  fe inv; inv_via_lazy<F>(inv, acc);
   for (u32 k = cnt; k-- > 0;) {
     fe x, y, z, pref;
     const uint4* p = jac + (j0 + k) * 6;

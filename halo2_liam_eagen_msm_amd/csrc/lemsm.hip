@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_precompute_mult_affine(const uint4* __r
     if (!G::is_identity(acc)) F::mul(pref, pref, acc.zzz);
     G::add(acc, p);
   }
-  fe inv; F::inv(inv, pref);
+  fe inv; inv_via_lazy<F>(inv, pref);
   for (u32 k = base - 1; k >= 1; k--) {
     const char* s = scratch + ((size_t)(k - 1) * n + j) * 160;
     typename G::pt q; G::load(q, s); fe pr; F::load(pr, s + 128);
@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_gen_walk(const uint4* __restrict__ q_af
     G::store(s, acc); F::store(s + 128, pref);
     F::mul(pref, pref, acc.zzz);     // walk points are never the identity for n < group order
   }
-  fe inv; F::inv(inv, pref);
+  fe inv; inv_via_lazy<F>(inv, pref);
   for (u32 i = cnt; i-- > 0;) {
     const char* s = scratch + ((size_t)i * nthreads + t) * 160;
     typename G::pt p; G::load(p, s); fe pr; F::load(pr, s + 128);
