@@ -16,8 +16,10 @@ enum { META_M = 0, META_TILES = 1, META_WORDS = 4, META_CLOCK = 8 /* 4 x u64 wri
 // ------------------------------------------------------------------------------------
 // level 1: segmented accumulation of the bucket-sorted entry list.
 // Thread t owns entries [t*L1, (t+1)*L1).  A segment (maximal run of one bucket inside the
-// chunk) that covers its whole bucket is stored to bucket_sum[key]; otherwise it becomes an
-// edge record (at most two per thread: first and last segment) for the next level.
+// chunk) that covers its whole bucket is stored to bucket_sum[key]; otherwise it is one PIECE of its
+// bucket (at most two per thread: the segment that reaches the chunk's end -> slot 2t+1, a segment that
+// begins at the chunk's start and ends earlier -> slot 2t) for the merge kernels below; rec_key[t] = the
+// bucket this chunk owns (the one that starts here and runs past the chunk's end), or KEY_NONE.
 // ------------------------------------------------------------------------------------
 template <class G, int WPS /* waves per SIMD the register budget is sized for */,
           bool ABI = false /* points in the C ABI's domain, accumulator and outputs in the scaled form: G::madd_abi */,
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
   }
   const u64 s64 = (u64)t * pl.L1;
   const u32 r0 = 2 * t;
-  if (s64 >= M) { rec_key[r0] = KEY_NONE; rec_key[r0 + 1] = KEY_NONE; return; }
+  if (s64 >= M) { rec_key[t] = KEY_NONE; return; }
   const u32 start = (u32)s64;
   const u32 end = (u32)min((u64)M, s64 + pl.L1);
 
@@ -57,8 +59,6 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
   u32 kend = bucket_start[key + 1];
   u32 kend2 = bucket_start[min(key + 2u, nkeys)], kend3 = bucket_start[min(key + 3u, nkeys)];
   u32 seg_begin = start;
-  u32 nrec = 0;
-  u32 first_key = KEY_NONE;
 
   typename G::pt acc; G::set_identity(acc);
   bool empty = true;          // acc == identity (tracked so that the loop tests a flag, not nine limbs)
@@ -68,11 +68,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
     if (complete) {
       G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc);
     } else {
-      u32 slot = r0 + nrec;
-      rec_key[slot] = key;
-      G::store(rec_pt + (size_t)slot * G::PT_BYTES, acc);
-      if (nrec == 0) first_key = key;
-      nrec++;
+      G::store(rec_pt + (size_t)(r0 + (seg_end == end ? 1u : 0u)) * G::PT_BYTES, acc);
     }
   };
 
@@ -146,132 +142,165 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
     u64* ck = reinterpret_cast<u64*>(meta + META_CLOCK);
     ck[2] = __builtin_amdgcn_s_memtime(); ck[3] = __builtin_amdgcn_s_memrealtime();
   }
-  // Filler rule (DESIGN.md "edge records"): a lone record is followed by an identity record of
-  // the same key, so that a bucket's run of records stays contiguous across threads (KEY_NONE is
-  // only ever written where no run can pass through).
-  if (nrec == 0) { rec_key[r0] = KEY_NONE; rec_key[r0 + 1] = KEY_NONE; }
-  else if (nrec == 1) {
-    typename G::pt id; G::set_identity(id);
-    rec_key[r0 + 1] = first_key;
-    G::store(rec_pt + (size_t)(r0 + 1) * G::PT_BYTES, id);
-  }
+  // this chunk owns the bucket of its last segment if that bucket starts here and continues in the next chunk
+  rec_key[t] = (seg_begin == kbeg && end != kend) ? key : KEY_NONE;
 }
 
 // ------------------------------------------------------------------------------------
-// level >= 2: segmented reduction of edge records (XYZZ + XYZZ).  Same completeness rule,
-// decided from the neighbouring record keys.  R = number of input records.
+// Edge-record merge.  k_accum1 cuts the bucket-sorted entry list into equal chunks regardless of bucket
+// boundaries, so a bucket that straddles chunk ends arrives in PIECES: one partial sum per chunk it touches.
+// Where the pieces lie follows from bucket_start[] and the chunk length alone -- chunk t keeps the sum of the
+// segment that reaches its END in slot 2t+1 ("last" record) and the sum of a segment that begins at its START
+// and ends earlier in slot 2t ("first" record) -- so no keys, fillers or compaction passes are needed: the
+// pieces of a bucket that starts in chunk ta and ends in chunk tb are the last records of ta..tb-1 plus
+// tb's first record (its last record if the bucket ends exactly where the chunk does).  The chunk a bucket
+// STARTS in owns it (rec_key[ta] = key).
+//   k_merge_pairs   one thread per chunk: a two-piece bucket (the common case: uniform digits put about one
+//                   bucket boundary into every chunk) is added and stored at once; longer ones are queued by size.
+//   k_merge_queues  3..8 pieces: one thread per queued bucket, serial.  9..32 pieces: one wave per bucket while
+//                   the queue is short (latency), else serial like the short ones (throughput).  More than 32:
+//                   slices of <= `slice` pieces, one wave each (lanes stride over the pieces, then a shuffle
+//                   tree); a bucket of several slices leaves one partial sum per slice.
+//   k_merge_final   one wave per multi-slice bucket adds its partials.
+// Depth: 1 addition for uniform scalars (was 8 + 4 x 6 through the segmented-scan levels), <= slice/64 + 6 + 6
+// for any input; the sum of a bucket is formed in piece order whatever the queue order, so results are
+// deterministic.
 // ------------------------------------------------------------------------------------
+enum { MQ_S = 0, MQ_M = 1, MQ_L = 2, MQ_F = 3, MQ_P = 4, MQ_WORDS = 8 };   // queue counters: short, medium, long slices, multi-slice buckets, partials
+struct MqLayout { u32 offS, offM, offL, offF, capS, capM, capL, capF, capP, slice, wave_th; };
+static const u32 MQ_DST_BUCKET = 0xffffffffu;
+
 template <class G>
-__global__ __launch_bounds__(256) void k_segreduce(u32 R, u32 L, u32 scaled /* k_accum1 ran in its ABI form */,
-                                                   const u32* __restrict__ in_key,
-                                                   const char* __restrict__ in_pt, char* __restrict__ bucket_sum,
-                                                   u32* __restrict__ out_key, char* __restrict__ out_pt) {
+__device__ __forceinline__ void merge_load_piece(typename G::pt& q, const char* __restrict__ rec_pt, u32 t, bool first_slot, u32 scaled) {
+  G::load(q, rec_pt + (size_t)(2u * t + (first_slot ? 0u : 1u)) * G::PT_BYTES);
+  if (scaled) G::unscale(q);                     // k_accum1's ABI form keeps (X, Y, 32 ZZ, 32 ZZZ)
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_merge_pairs(GroupPlan pl, u32 scaled, MqLayout lay, const u32* __restrict__ bucket_start,
+                                                     const u32* __restrict__ meta, const u32* __restrict__ rec_key,
+                                                     const char* __restrict__ rec_pt, char* __restrict__ bucket_sum,
+                                                     u32* __restrict__ mq_cnt, uint4* __restrict__ mq_items) {
+  __shared__ u32 lc[5], lbase[5];
   const u32 t = blockIdx.x * 256 + threadIdx.x;
-  const u64 c0_64 = (u64)t * L;
-  if (c0_64 >= R) return;
-  const u32 c0 = (u32)c0_64;
-  const u32 c1 = (u32)min((u64)R, c0_64 + L);
-  const u32 r0 = 2 * t;
-  const u32 prev_key = c0 > 0 ? in_key[c0 - 1] : KEY_NONE;
-  const u32 next_key = c1 < R ? in_key[c1] : KEY_NONE;
-
-  typename G::pt acc; G::set_identity(acc);
-  u32 cur = KEY_NONE;         // key of the open segment
-  bool open_from_start = false;
-  u32 nrec = 0, first_key = KEY_NONE;
-
-  auto flush = [&](bool touches_end) {
-    bool complete = !(open_from_start && prev_key == cur) && !(touches_end && next_key == cur);
-    if (complete) {
-      typename G::pt sc = acc;
-      if (scaled) G::scale(sc);                     // bucket_sum[] then holds the scaled form (xyzz29.cuh)
-      G::store(bucket_sum + (size_t)cur * G::PT_BYTES, sc);
-    } else {
-      u32 slot = r0 + nrec;
-      out_key[slot] = cur;
-      G::store(out_pt + (size_t)slot * G::PT_BYTES, acc);
-      if (nrec == 0) first_key = cur;
-      nrec++;
+  if (threadIdx.x < 5) lc[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 key = t < pl.nthr1 ? rec_key[t] : KEY_NONE;
+  u32 P = 0, lastfirst = 0, cls = 0, loff = 0, nsub = 0, poff = 0, foff = 0;
+  if (key != KEY_NONE) {
+    const u32 e = bucket_start[key + 1], M = meta[META_M];
+    const u32 tb = (e - 1u) / pl.L1;
+    P = tb - t + 1u;                              // >= 2: the owner's segment ran into its chunk end
+    lastfirst = ((u64)(tb + 1u) * pl.L1 == (u64)e || e == M) ? 0u : 1u;
+    cls = P == 2 ? 1u : (P <= 8 ? 2u : (P <= 32 ? 3u : 4u));
+    if (cls == 2) loff = atomicAdd(&lc[MQ_S], 1u);
+    else if (cls == 3) loff = atomicAdd(&lc[MQ_M], 1u);
+    else if (cls == 4) {
+      nsub = (P + lay.slice - 1u) / lay.slice;
+      loff = atomicAdd(&lc[MQ_L], nsub);
+      if (nsub > 1) { poff = atomicAdd(&lc[MQ_P], nsub); foff = atomicAdd(&lc[MQ_F], 1u); }
     }
-  };
-
-  for (u32 i = c0; i < c1; i++) {
-    u32 k = in_key[i];
-    if (k == KEY_NONE) {
-      if (cur != KEY_NONE) { flush(false); cur = KEY_NONE; }
-      continue;
-    }
-    if (k != cur) {
-      if (cur != KEY_NONE) flush(false);
-      cur = k;
-      open_from_start = (i == c0);
-      G::set_identity(acc);
-    }
-    typename G::pt q; G::load(q, in_pt + (size_t)i * G::PT_BYTES);
-    if (scaled) G::unscale(q);                     // k_accum1's records are (X, Y, 32 ZZ, 32 ZZZ); ours are plain
-    G::add(acc, q);
   }
-  if (cur != KEY_NONE) flush(true);
-  if (nrec == 0) { out_key[r0] = KEY_NONE; out_key[r0 + 1] = KEY_NONE; }
-  else if (nrec == 1) {
-    typename G::pt id; G::set_identity(id);
-    out_key[r0 + 1] = first_key;
-    G::store(out_pt + (size_t)(r0 + 1) * G::PT_BYTES, id);
+  __syncthreads();
+  if (threadIdx.x < 5) lbase[threadIdx.x] = lc[threadIdx.x] ? atomicAdd(&mq_cnt[threadIdx.x], lc[threadIdx.x]) : 0u;
+  __syncthreads();
+  if (cls == 2) { u32 i = lbase[MQ_S] + loff; if (i < lay.capS) mq_items[lay.offS + i] = make_uint4(key, t, P | (lastfirst << 31), MQ_DST_BUCKET); }
+  else if (cls == 3) { u32 i = lbase[MQ_M] + loff; if (i < lay.capM) mq_items[lay.offM + i] = make_uint4(key, t, P | (lastfirst << 31), MQ_DST_BUCKET); }
+  else if (cls == 4) {
+    const u32 i0 = lbase[MQ_L] + loff, p0 = lbase[MQ_P] + poff;
+    for (u32 k = 0; k < nsub; k++) {
+      const u32 cnt = min(lay.slice, P - k * lay.slice);
+      const u32 lf = (k + 1 == nsub) ? lastfirst : 0u;
+      if (i0 + k < lay.capL) mq_items[lay.offL + i0 + k] = make_uint4(key, t + k * lay.slice, cnt | (lf << 31), nsub > 1 ? p0 + k : MQ_DST_BUCKET);
+    }
+    if (nsub > 1) { u32 f = lbase[MQ_F] + foff; if (f < lay.capF) mq_items[lay.offF + f] = make_uint4(key, p0, nsub, 0); }
+  }
+  if (cls == 1) {
+    typename G::pt acc, q;
+    merge_load_piece<G>(acc, rec_pt, t, false, scaled);
+    merge_load_piece<G>(q, rec_pt, t + 1u, lastfirst != 0, scaled);
+    G::add(acc, q);
+    if (scaled) G::scale(acc);                    // bucket_sum[] holds the scaled form throughout (xyzz29.cuh)
+    G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc);
   }
 }
 
-// ------------------------------------------------------------------------------------
-// later edge-record levels: one record per lane, wavefront segmented scan (6 shuffle + add
-// steps), so a level is 6 additions deep and shrinks the record list 32x.  A run that lies inside
-// its wave goes to bucket_sum; per wave at most two edge records survive (its first run if it
-// continues from the previous wave, its last run if it continues into the next), written with
-// the same filler rule as above.
-// ------------------------------------------------------------------------------------
+// lane 0 of the wave ends up with the sum of the lanes' points (lanes >= nact hold the identity)
 template <class G>
-__global__ __launch_bounds__(256) void k_segwave(u32 R, u32 scaled, const u32* __restrict__ in_key, const char* __restrict__ in_pt,
-                                                 char* __restrict__ bucket_sum, u32* __restrict__ out_key,
-                                                 char* __restrict__ out_pt) {
-  const u32 gid = blockIdx.x * 256 + threadIdx.x;
-  const u32 lane = threadIdx.x & 63u, wave = gid >> 6;
-  const u32 wbase = wave << 6;
-  if (wbase >= R) return;
-  u32 key = gid < R ? in_key[gid] : KEY_NONE;
-  typename G::pt acc;
-  if (key != KEY_NONE) G::load(acc, in_pt + (size_t)gid * G::PT_BYTES); else G::set_identity(acc);
-  // neighbours across the wave boundary
-  u32 prev_glob = wbase > 0 ? in_key[wbase - 1] : KEY_NONE;
-  u32 next_glob = wbase + 64 < R ? in_key[wbase + 64] : KEY_NONE;
-  u32 knext = __shfl_down(key, 1); if (lane == 63) knext = next_glob;
-  const u32 key0 = __shfl(key, 0);
+__device__ __forceinline__ void merge_wave_tree(typename G::pt& acc, u32 lane, u32 nact) {
 #pragma unroll 1
-  for (int d = 1; d < 64; d <<= 1) {
-    u32 k2 = __shfl_up(key, d);
-    typename G::pt q; G::shfl_up(q, acc, d);
-    bool take = lane >= (u32)d && key != KEY_NONE && k2 == key;
-    if (!take) G::set_identity(q);
+  for (u32 d = 32; d >= 1; d >>= 1) {
+    if (d >= nact) continue;                      // wave-uniform: nothing lives at lane >= d yet
+    typename G::pt q; G::shfl(q, acc, (int)((lane + d) & 63u));
+    if (lane >= d || lane + d >= nact) G::set_identity(q);
     G::add(acc, q);
   }
-  const bool last_of_run = key != KEY_NONE && knext != key;         // run ends inside the wave
-  const bool open_end = key != KEY_NONE && lane == 63 && knext == key;   // run continues into the next wave
-  const bool from_lane0 = key == key0;                                // run started at lane 0
-  const bool before = from_lane0 && prev_glob == key && key != KEY_NONE;
-  const bool holder = last_of_run || open_end;                       // lane holding its run's in-wave sum
-  const bool edge = holder && (before || open_end);
-  if (holder && !edge) { typename G::pt sc = acc; if (scaled) G::scale(sc); G::store(bucket_sum + (size_t)key * G::PT_BYTES, sc); }
-  unsigned long long em = __ballot(edge);
-  const u32 nedge = __popcll(em);
-  const u32 o0 = 2 * wave;
-  if (edge) {
-    u32 rank = __popcll(em & ((1ull << lane) - 1ull));
-    out_key[o0 + rank] = key;
-    G::store(out_pt + (size_t)(o0 + rank) * G::PT_BYTES, acc);
-    if (nedge == 1) {            // lone record: identity filler of the same key keeps the run contiguous
-      typename G::pt id; G::set_identity(id);
-      out_key[o0 + 1] = key;
-      G::store(out_pt + (size_t)(o0 + 1) * G::PT_BYTES, id);
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_merge_queues(u32 nblk_short, u32 scaled, MqLayout lay, const u32* __restrict__ mq_cnt,
+                                                      const uint4* __restrict__ mq_items, const char* __restrict__ rec_pt,
+                                                      char* __restrict__ partial, char* __restrict__ bucket_sum) {
+  const u32 cS = min(mq_cnt[MQ_S], lay.capS), cMall = min(mq_cnt[MQ_M], lay.capM), cL = min(mq_cnt[MQ_L], lay.capL);
+  const bool m_serial = cMall > lay.wave_th;
+  if (blockIdx.x < nblk_short) {
+    // one thread per queued bucket; the two classes start on wave boundaries so that a wave's trip counts are alike
+    const u32 v = blockIdx.x * 256 + threadIdx.x;
+    const u32 rS = (cS + 63u) & ~63u, cM = m_serial ? cMall : 0u;
+    uint4 it;
+    if (v < rS) { if (v >= cS) return; it = mq_items[lay.offS + v]; }
+    else { if (v - rS >= cM) return; it = mq_items[lay.offM + (v - rS)]; }
+    const u32 key = it.x, t0 = it.y, n = it.z & 0x7fffffffu, lf = it.z >> 31;
+    typename G::pt acc, q;
+    merge_load_piece<G>(acc, rec_pt, t0, false, scaled);
+#pragma unroll 1
+    for (u32 j = 1; j < n; j++) {
+      merge_load_piece<G>(q, rec_pt, t0 + j, j + 1 == n && lf, scaled);
+      G::add(acc, q);
+    }
+    if (scaled) G::scale(acc);
+    G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc);
+    return;
+  }
+  // one wave per medium bucket / per slice of a long one
+  const u32 lane = threadIdx.x & 63u;
+  const u32 nwaves = (gridDim.x - nblk_short) * 4u;
+  const u32 cM = m_serial ? 0u : cMall;
+#pragma unroll 1
+  for (u32 w = (blockIdx.x - nblk_short) * 4u + (threadIdx.x >> 6); w < cM + cL; w += nwaves) {
+    const uint4 it = w < cM ? mq_items[lay.offM + w] : mq_items[lay.offL + (w - cM)];
+    const u32 key = it.x, t0 = it.y, n = it.z & 0x7fffffffu, lf = it.z >> 31, dst = it.w;
+    typename G::pt acc, q; G::set_identity(acc);
+#pragma unroll 1
+    for (u32 j = lane; j < n; j += 64) {
+      merge_load_piece<G>(q, rec_pt, t0 + j, j + 1 == n && lf, scaled);
+      G::add(acc, q);
+    }
+    merge_wave_tree<G>(acc, lane, min(n, 64u));
+    if (lane == 0) {
+      if (dst == MQ_DST_BUCKET) { if (scaled) G::scale(acc); G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc); }
+      else if (dst < lay.capP) G::store(partial + (size_t)dst * G::PT_BYTES, acc);      // plain form
     }
   }
-  if (nedge == 0 && lane == 0) { out_key[o0] = KEY_NONE; out_key[o0 + 1] = KEY_NONE; }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_merge_final(u32 scaled, MqLayout lay, const u32* __restrict__ mq_cnt, const uint4* __restrict__ mq_items,
+                                                     const char* __restrict__ partial, char* __restrict__ bucket_sum) {
+  const u32 cF = min(mq_cnt[MQ_F], lay.capF);
+  const u32 lane = threadIdx.x & 63u, nwaves = gridDim.x * 4u;
+#pragma unroll 1
+  for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < cF; w += nwaves) {
+    const uint4 it = mq_items[lay.offF + w];
+    const u32 key = it.x, p0 = it.y, n = it.z;
+    typename G::pt acc, q; G::set_identity(acc);
+#pragma unroll 1
+    for (u32 j = lane; j < n; j += 64) {
+      if (p0 + j < lay.capP) { G::load(q, partial + (size_t)(p0 + j) * G::PT_BYTES); G::add(acc, q); }
+    }
+    merge_wave_tree<G>(acc, lane, min(n, 64u));
+    if (lane == 0) { if (scaled) G::scale(acc); G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc); }
+  }
 }
 
 // ------------------------------------------------------------------------------------

@@ -14,6 +14,8 @@
 
 #include "../../include/lemsm.h"
 #include "hostmath.hpp"
+#include "hostpool.hpp"
+#include <memory>
 #include "kernels.cuh"
 #include "rccl_dyn.hpp"
 #include "divisor.cuh"
@@ -46,8 +48,9 @@ const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUN
 }  // namespace
 // heavy kernels are instantiated in inst_*.hip
 #define LEMSM_EXTERN_G(G)                                                                                   \
-  extern template __global__ void lemsm::k_segreduce<G>(u32, u32, u32, const u32*, const char*, char*, u32*, char*); \
-  extern template __global__ void lemsm::k_segwave<G>(u32, u32, const u32*, const char*, char*, u32*, char*);                     \
+  extern template __global__ void lemsm::k_merge_pairs<G>(GroupPlan, u32, MqLayout, const u32*, const u32*, const u32*, const char*, char*, u32*, uint4*); \
+  extern template __global__ void lemsm::k_merge_queues<G>(u32, u32, MqLayout, const u32*, const uint4*, const char*, char*, char*); \
+  extern template __global__ void lemsm::k_merge_final<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*); \
   extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*); \
   extern template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*);
 #define LEMSM_EXTERN_ACC(G, W) \
@@ -101,11 +104,13 @@ struct lemsm_ctx {
   double dw_phase_ms[4] = {0, 0, 0, 0};   // lhs witness: MSM core, point lists, merge forest, coefficient download
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
+  void* h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for the read-back of one call's records (one async copy, no pageable bounce)
+  std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_seg_records = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0;
+  long opt_host_threads = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
-  bool want_raw_records = false;                  // lemsm_msm_device: skip the per-window sums, it folds the raw records itself
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
   double accum_clock_mhz = 0;                     // shader clock the accumulate kernel of the last call sustained (in-kernel stamps)
@@ -138,6 +143,26 @@ int reserve(lemsm_ctx* ctx, DevBuf& b, size_t bytes) {
   if (e != hipSuccess) { b.p = nullptr; return fail(ctx, LEMSM_ERR_NOMEM, "hipMalloc failed: " + std::string(hipGetErrorString(e))); }
   b.cap = want;
   return LEMSM_OK;
+}
+
+// pinned host staging buffer of the context
+int reserve_pinned(lemsm_ctx* ctx, size_t bytes) {
+  if (ctx->h_pin_cap >= bytes) return LEMSM_OK;
+  if (ctx->h_pin) { HIPCHK(ctx, hipHostFree(ctx->h_pin)); ctx->h_pin = nullptr; ctx->h_pin_cap = 0; }
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault);
+  if (e != hipSuccess) { ctx->h_pin = nullptr; return fail(ctx, LEMSM_ERR_NOMEM, "hipHostMalloc failed: " + std::string(hipGetErrorString(e))); }
+  ctx->h_pin_cap = want;
+  return LEMSM_OK;
+}
+
+// host tail in parallel: jobs are independent pieces of ~10 us (one window's records); option "host_threads":
+// 0 = auto (up to 8 threads including the caller, never more than the CPUs this process may use), 1 = serial
+void host_parallel(lemsm_ctx* ctx, int njobs, const std::function<void(int)>& fn) {
+  if (!ctx || njobs <= 1 || ctx->opt_host_threads == 1) { for (int i = 0; i < njobs; i++) fn(i); return; }
+  int want = ctx->opt_host_threads > 1 ? (int)ctx->opt_host_threads : std::min(8, lemsm::host::Pool::usable_cpus());
+  if (!ctx->pool || ctx->pool->workers() != want - 1) ctx->pool.reset(new lemsm::host::Pool(std::max(0, want - 1)));
+  ctx->pool->run(njobs, fn);
 }
 
 // ---- big-integer helpers on 8 x u32 (host) ----
@@ -321,16 +346,29 @@ struct GroupWs {
   unsigned long long* signbm;
   uint4* tile_info;
   u32* entries; u32* sorted;
-  u32* rec_key_a; char* rec_pt_a; u32* rec_key_b; char* rec_pt_b;
+  u32* rec_key; char* rec_pt;      // k_accum1's pieces: the bucket a chunk owns, and its first / last partial sums (2 slots per chunk)
+  u32* mq_cnt; uint4* mq_items; char* mq_partial; MqLayout mq;   // merge queues (kernels_ec.cuh)
   size_t zero_begin, zero_bytes;   // contiguous region to memset(0) per group (offset from base)
   size_t total;
   std::vector<size_t> guards;      // option ws_canary: offsets of the 256-byte guard behind every sub-buffer
 };
 
-const u32 L2_RECORDS = 8;     // records per thread at the first edge-record level
+// merge queues of one group (kernels_ec.cuh "edge-record merge").  A bucket of P >= 2 pieces spans P chunks and
+// neighbouring buckets share at most one chunk, so at most nthr1 / (P - 1) buckets have P or more pieces.
+MqLayout make_mq_layout(const lemsm_ctx* ctx, u32 nthr1) {
+  MqLayout m; memset(&m, 0, sizeof m);
+  m.slice = ctx && ctx->opt_merge_slice ? (u32)ctx->opt_merge_slice : 512u;      // pieces per wave of a long bucket
+  m.wave_th = ctx && ctx->opt_merge_wave_th ? (u32)ctx->opt_merge_wave_th - 1u : 2048u;   // 9..32-piece buckets: one wave each up to this many, serial beyond
+  m.capS = nthr1 / 2 + 2; m.capM = nthr1 / 8 + 2;
+  m.capF = nthr1 / m.slice + 2;                  // buckets of more than one slice
+  m.capL = nthr1 / 32 + nthr1 / m.slice + 4;     // slices: sum ceil(P / slice) over buckets of > 32 pieces
+  m.capP = 2 * (nthr1 / m.slice) + 4;            // partial sums (multi-slice buckets only)
+  m.offS = 0; m.offM = m.offS + m.capS; m.offL = m.offM + m.capM; m.offF = m.offL + m.capL;
+  return m;
+}
 
 const size_t WS_GUARD = 256;
-GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t ntasks_total, size_t ptb, bool guard = false) {
+GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, const MqLayout& mq, size_t ptb, bool guard = false) {
   GroupWs w; size_t off = 0;
   // option ws_canary (debug / fuzz): every sub-buffer is followed by a guard that run_group fills with a pattern and
   // checks when the group is done -- an overrun of ANY sub-buffer shows up, not only one past the group's end
@@ -344,6 +382,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   // zeroed region first: bin_total, bin_cursor, bucket_count, bucket_cursor, bucket sums
   size_t z0 = off;
   size_t o_err = take(64);
+  size_t o_mqcnt = take(MQ_WORDS * 4);
   size_t o_bin_total = take(MAX_BINS * 4), o_bin_cursor = take(MAX_BINS * 4);
   size_t o_bcount = take((size_t)NBpad * 4), o_bcursor = take((size_t)NBpad * 4);
   size_t o_arena = take((size_t)ar.total_points * ptb);
@@ -356,9 +395,9 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
   size_t o_sbm = take(pl.c == 17 ? (size_t)(pl.w1 - pl.w0) * ((pl.n + 63) / 64) * 8 + 16 : 16);
   size_t Mmax = (size_t)pl.n * (pl.w1 - pl.w0);
   size_t o_entries = take(Mmax * 4 + 4 * (size_t)pl.L1 + 512), o_sorted = take(Mmax * 4 + 4 * (size_t)pl.L1 + 512);   // (+ slack: the entry ring stages whole 64-byte blocks)
-  size_t R1 = 2 * (size_t)pl.nthr1;
-  size_t R2 = 2 * ((R1 + 1) / 2);   // first edge level writes 2 records per `per` >= 2 inputs (option seg_records)
-  size_t o_rka = take(R1 * 4 + 16), o_rpa = take(R1 * ptb + 256), o_rkb = take(R2 * 4 + 16), o_rpb = take(R2 * ptb + 256);
+  w.mq = mq;
+  size_t o_rk = take((size_t)pl.nthr1 * 4 + 16), o_rp = take(2 * (size_t)pl.nthr1 * ptb + 256);
+  size_t o_mqi = take(((size_t)mq.offF + mq.capF) * 16), o_mqp = take((size_t)mq.capP * ptb + 256);
   w.total = off;
   if (base) {
     w.err = (u32*)(base + o_err);
@@ -368,7 +407,8 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, size_t nta
     w.bin_start = (u32*)(base + o_bin_start); w.tile_prefix = (u32*)(base + o_tile_prefix); w.meta = (u32*)(base + o_meta);
     w.bucket_start = (u32*)(base + o_bstart); w.block_counts = (u32*)(base + o_blockc); w.dig16 = (uint16_t*)(base + o_dig); w.tile_info = (uint4*)(base + o_tinfo); w.signbm = (unsigned long long*)(base + o_sbm);
     w.entries = (u32*)(base + o_entries); w.sorted = (u32*)(base + o_sorted);
-    w.rec_key_a = (u32*)(base + o_rka); w.rec_pt_a = base + o_rpa; w.rec_key_b = (u32*)(base + o_rkb); w.rec_pt_b = base + o_rpb;
+    w.rec_key = (u32*)(base + o_rk); w.rec_pt = base + o_rp;
+    w.mq_cnt = (u32*)(base + o_mqcnt); w.mq_items = (uint4*)(base + o_mqi); w.mq_partial = base + o_mqp;
   }
   w.zero_begin = z0; w.zero_bytes = zend - z0;
   return w;
@@ -515,7 +555,8 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   PyrTask* d_tasks = (PyrTask*)pit->second.buf.p;
   CopyTask* d_copy = (CopyTask*)((char*)pit->second.buf.p + align_up(ntasks_total * sizeof(PyrTask), 256));
   const size_t ptb = G::PT_BYTES;
-  GroupWs w = carve(ws_base, pl, ar, ntasks_total, ptb, ctx->opt_ws_canary != 0);
+  const MqLayout mq = make_mq_layout(ctx, pl.nthr1);
+  GroupWs w = carve(ws_base, pl, ar, mq, ptb, ctx->opt_ws_canary != 0);
   // the kernels below size LDS arrays and workspace slots by these limits: never launch a plan that exceeds them
   if (pl.nbins > MAX_BINS || pl.BW > BW_MAX || pl.LB > MAX_LB || pl.spb > 4 * STAGE || (pl.c && pl.dstride < pl.n) || pl.T2 > STAGE2 || pl.bin_cap > BIN_CAP)
     return fail(ctx, LEMSM_ERR_HIP, "internal: window-group plan exceeds a kernel limit (bins " + std::to_string(pl.nbins) + ", bins per window " + std::to_string(pl.BW) + ")");
@@ -561,48 +602,37 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     // register-budget variant of the accumulate kernel (lazy field: 2, 3 or 4 waves per SIMD)
     int wps = G::CONVERTED_DOMAIN ? (ctx->opt_accum_waves ? (int)ctx->opt_accum_waves : 3) : 4;
     if constexpr (G::CONVERTED_DOMAIN) {
-      if (wps == 2) hipLaunchKernelGGL((k_accum1<G, 2>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
-      else if (wps == 4) hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
-      else if (abi && (pl.L1 & 15u) == 0 && pl.L1 >= 32 && ctx->opt_entry_ring != 1) hipLaunchKernelGGL((k_accum1<G, 3, true, true>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
-      else if (abi) hipLaunchKernelGGL((k_accum1<G, 3, true>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
-      else hipLaunchKernelGGL((k_accum1<G, 3>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      if (wps == 2) hipLaunchKernelGGL((k_accum1<G, 2>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key, w.rec_pt);
+      else if (wps == 4) hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key, w.rec_pt);
+      else if (abi && (pl.L1 & 15u) == 0 && pl.L1 >= 32 && ctx->opt_entry_ring != 1) hipLaunchKernelGGL((k_accum1<G, 3, true, true>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key, w.rec_pt);
+      else if (abi) hipLaunchKernelGGL((k_accum1<G, 3, true>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key, w.rec_pt);
+      else hipLaunchKernelGGL((k_accum1<G, 3>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key, w.rec_pt);
     } else {
-      hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key_a, w.rec_pt_a);
+      hipLaunchKernelGGL((k_accum1<G, 4>), grid, blk, 0, st, pl, d_sorted, d_bstart, w.meta, (const uint4*)d_points, bsum, w.rec_key, w.rec_pt);
     }
   }
   HIPCHK(ctx, hipEventRecord(ev_acc1, s_acc));
   st = s_tail;
   HIPCHK(ctx, hipStreamWaitEvent(s_tail, ev_acc1, 0));
 
-  // edge-record levels
+  // edge-record merge (kernels_ec.cuh): pairs at once, longer buckets through the size-class queues
   {
-    u32 R = 2 * pl.nthr1;
-    u32* ik = w.rec_key_a; char* ip = w.rec_pt_a; u32* ok = w.rec_key_b; char* op = w.rec_pt_b;
-    // first level: 8 records per thread, serial (work-efficient while most records are real);
-    // later levels: one record per lane with a wavefront segmented scan (6 additions deep, 32x shrink)
-    {
-      u32 per = ctx->opt_seg_records ? (u32)ctx->opt_seg_records : L2_RECORDS;
-      u32 nthr = (R + per - 1) / per;
-      hipLaunchKernelGGL((k_segreduce<G>), dim3((nthr + 255) / 256), dim3(256), 0, st, R, per, abi ? 1u : 0u, ik, ip,
-                         w.arena + (size_t)ar.bucket_off * ptb, ok, op);
-      R = 2 * nthr;
-      std::swap(ik, ok); std::swap(ip, op);
-    }
-    for (;;) {
-      u32 nwaves = (R + 63) / 64;
-      hipLaunchKernelGGL((k_segwave<G>), dim3((nwaves + 3) / 4), dim3(256), 0, st, R, abi ? 1u : 0u, ik, ip,
-                         w.arena + (size_t)ar.bucket_off * ptb, ok, op);
-      if (nwaves == 1) break;
-      R = 2 * nwaves;
-      std::swap(ik, ok); std::swap(ip, op);
-    }
+    const u32 sc = abi ? 1u : 0u;
+    char* bsum = w.arena + (size_t)ar.bucket_off * ptb;
+    hipLaunchKernelGGL((k_merge_pairs<G>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, sc, mq, d_bstart, w.meta, w.rec_key, w.rec_pt, bsum, w.mq_cnt, w.mq_items);
+    // grid of the queue kernel: the host does not know the queue lengths, so the serial part gets the bound of its two
+    // classes (blocks past the counts exit at once) and the wave part a fixed number of waves that stride over the items
+    const u32 nblk_short = (mq.capS + mq.capM + 64 + 255) / 256;
+    const u32 nblk_wave = std::min(512u, std::max(1u, (mq.capM + mq.capL + 3) / 4));
+    hipLaunchKernelGGL((k_merge_queues<G>), dim3(nblk_short + nblk_wave), dim3(256), 0, st, nblk_short, sc, mq, w.mq_cnt, w.mq_items, w.rec_pt, w.mq_partial, bsum);
+    hipLaunchKernelGGL((k_merge_final<G>), dim3(std::min(64u, std::max(1u, (mq.capF + 3) / 4))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.mq_partial, bsum);
   }
   // bucket reduction pyramid: one launch per step while a step is wide, then all remaining steps (and the copy of
   // U_{L-1}) in one launch of one block per window (k_pyramid_tail)
   {
     size_t toff = 0;
     u32 first_fused = L + 1;
-    if (ctx->opt_pyr_fuse != 1)
+    if (ctx->opt_pyr_fuse == 2)
       for (u32 s = 1; s <= L; s++) {
         bool fits = true;
         for (u32 q = s; q <= L; q++) if ((size_t)pp.steps[q - 1].size() * pp.step_max_count[q - 1] > 2048) fits = false;
@@ -640,11 +670,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   return LEMSM_OK;
 }
 
-size_t group_ws_bytes(const GroupPlan& pl, u32 nbp, u32 L, size_t ptb, bool guard) {
+size_t group_ws_bytes(const lemsm_ctx* ctx, const GroupPlan& pl, u32 nbp, u32 L, size_t ptb, bool guard) {
   u32 gw = pl.w1 - pl.w0;
   ArenaLayout ar = make_arena(pl.nbins << pl.LB, nbp, gw, L);
-  size_t ntasks = (size_t)(L + 2) * (L + 2);
-  GroupWs w = carve(nullptr, pl, ar, ntasks, ptb, guard);
+  GroupWs w = carve(nullptr, pl, ar, make_mq_layout(ctx, pl.nthr1), ptb, guard);
   return w.total + 4096;
 }
 
@@ -692,14 +721,12 @@ host::fe reduce_raw29(const int32_t* l) {
 }
 
 template <class P64, class G>
-void from_device_records(const std::vector<char>& raw, std::vector<host::pt>& out) {
-  size_t n = raw.size() / G::PT_BYTES;
-  out.resize(n);
+void from_device_records(const char* raw, size_t n, host::pt* out) {
   if constexpr (!G::CONVERTED_DOMAIN) {
-    memcpy(out.data(), raw.data(), n * sizeof(host::pt));
+    memcpy(out, raw, n * sizeof(host::pt));
   } else {
     for (size_t i = 0; i < n; i++) {
-      const int32_t* l = reinterpret_cast<const int32_t*>(raw.data() + i * G::PT_BYTES);
+      const int32_t* l = reinterpret_cast<const int32_t*>(raw + i * G::PT_BYTES);
       bool zz_zero = true;
       for (int k = 0; k < 9; k++) zz_zero &= (l[18 + k] == 0);
       if (zz_zero) { memset(&out[i], 0, sizeof(host::pt)); continue; }
@@ -755,8 +782,8 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
     u32 sn0 = (u32)std::min(SLAB, n), snl = (u32)(n - (nslabs - 1) * SLAB);
     for (u32 g0 = wb; g0 < we; g0 += gsz) {
       u32 g1 = std::min(we, g0 + gsz);
-      size_t bytes = group_ws_bytes(make_group_plan(ctx, sn0, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0);
-      if (snl != sn0) bytes = std::max(bytes, group_ws_bytes(make_group_plan(ctx, snl, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0));
+      size_t bytes = group_ws_bytes(ctx, make_group_plan(ctx, sn0, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0);
+      if (snl != sn0) bytes = std::max(bytes, group_ws_bytes(ctx, make_group_plan(ctx, snl, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0));
       groups.push_back({g0, g1, ws_total});
       ws_total += align_up(bytes + 8192, 256);     // (+ slack for the 16-entry rounding of the accumulate chunk, see make_group_plan)
     }
@@ -830,7 +857,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
       // the group's non-canonical-scalar flag (first 8 bytes of its workspace) survives the workspace reuse
       HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT, ws_base + gr.off, 8, hipMemcpyDeviceToDevice, s_tail));
       {
-        GroupWs gw_ = carve(ws_base + gr.off, pl, make_arena(pl.nbins << pl.LB, nbp, gr.g1 - gr.g0, L), 0, ptb, ctx->opt_ws_canary != 0);
+        GroupWs gw_ = carve(ws_base + gr.off, pl, make_arena(pl.nbins << pl.LB, nbp, gr.g1 - gr.g0, L), make_mq_layout(ctx, pl.nthr1), ptb, ctx->opt_ws_canary != 0);
         HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT + 16, gw_.meta + META_CLOCK, 32, hipMemcpyDeviceToDevice, s_tail));
       }
     }
@@ -855,10 +882,21 @@ int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size
   raw.resize(raw_bytes);
   const size_t nerr = wr.nslabs * wr.ng;
   std::vector<u32> errw(std::max<size_t>(nerr, 1) * (wr.err_slot / 4));
-  if (raw_bytes) HIPCHK(ctx, hipMemcpyAsync(raw.data(), d_raw, raw_bytes, hipMemcpyDeviceToHost, s_tail));
-  if (nerr) HIPCHK(ctx, hipMemcpyAsync(errw.data(), wr.d_err, nerr * wr.err_slot, hipMemcpyDeviceToHost, s_tail));
+  // read-back through the context's pinned buffer: records and error words sit next to each other in the workspace,
+  // so a single-GPU call is ONE asynchronous copy (pageable destinations made two staged copies with ~25 us gaps)
+  const size_t err_bytes = nerr * wr.err_slot;
+  { int rcp = reserve_pinned(ctx, raw_bytes + err_bytes + 64); if (rcp) return rcp; }
+  char* hp = (char*)ctx->h_pin;
+  if (d_raw == wr.d_out && raw_bytes == wr.send_bytes() && raw_bytes + err_bytes) {
+    HIPCHK(ctx, hipMemcpyAsync(hp, d_raw, raw_bytes + err_bytes, hipMemcpyDeviceToHost, s_tail));   // d_err follows d_out (run_windows_enqueue)
+  } else {
+    if (raw_bytes) HIPCHK(ctx, hipMemcpyAsync(hp, d_raw, raw_bytes, hipMemcpyDeviceToHost, s_tail));
+    if (err_bytes) HIPCHK(ctx, hipMemcpyAsync(hp + raw_bytes, wr.d_err, err_bytes, hipMemcpyDeviceToHost, s_tail));
+  }
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s_tail));
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+  if (raw_bytes) memcpy(raw.data(), hp, raw_bytes);
+  if (err_bytes) memcpy(errw.data(), hp + raw_bytes, err_bytes);
   float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
   ctx->t_total_ms = ms;
   for (size_t k = 0; k < wr.nslabs; k++)   // non-canonical scalars (>= field order) are rejected, never bucketed
@@ -882,18 +920,19 @@ int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size
 
 // host: records of nw windows = sum over the slabs of one rank's record area (raw: nslabs blocks of out_slab bytes)
 template <class P64, class G>
-void sum_slab_records(const char* raw, size_t out_slab, size_t nslabs, u32 nw, u32 L, std::vector<host::pt>& host_out) {
+void sum_slab_records(lemsm_ctx* ctx, const char* raw, size_t out_slab, size_t nslabs, u32 nw, u32 L, std::vector<host::pt>& host_out) {
   typedef host::HG<P64> HGp;
   const size_t ptb = G::PT_BYTES;
   host_out.assign((size_t)nw * (L + 1), HGp::identity());
-  std::vector<host::pt> tmp;
-  std::vector<char> one((size_t)nw * (L + 1) * ptb);
-  for (size_t k = 0; k < nslabs && nw; k++) {
-    memcpy(one.data(), raw + k * out_slab, one.size());
-    from_device_records<P64, G>(one, tmp);
-    if (k == 0) host_out = tmp;
-    else for (size_t i = 0; i < tmp.size(); i++) host_out[i] = HGp::add(host_out[i], tmp[i]);
-  }
+  host_parallel(ctx, (int)nw, [&](int w) {        // one job per window: its L + 1 records of every slab
+    std::vector<host::pt> tmp(L + 1);
+    host::pt* dst = host_out.data() + (size_t)w * (L + 1);
+    for (size_t k = 0; k < nslabs; k++) {
+      from_device_records<P64, G>(raw + k * out_slab + (size_t)w * (L + 1) * ptb, L + 1, tmp.data());
+      if (k == 0) memcpy(dst, tmp.data(), (L + 1) * sizeof(host::pt));
+      else for (u32 i = 0; i <= L; i++) dst[i] = HGp::add(dst[i], tmp[i]);
+    }
+  });
 }
 
 // Generic windowed bucket pipeline over window range [wb,we): fills host_out with
@@ -911,7 +950,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   std::vector<char> raw;
   rc = run_windows_finish(ctx, wr, wr.d_out, wr.send_bytes(), raw);
   if (rc) return rc;
-  sum_slab_records<P64, G>(raw.data(), wr.out_slab, wr.nslabs, nw, L, host_out);
+  sum_slab_records<P64, G>(ctx, raw.data(), wr.out_slab, wr.nslabs, nw, L, host_out);
   return LEMSM_OK;
 }
 
@@ -924,6 +963,13 @@ host::pt window_sum(const host::pt* rec, u32 L) {
   return G::add(acc, rec[0]);
 }
 
+// the window sums of one call, one pool job per window (L doublings + L + 1 additions each)
+template <class P64>
+void window_sums_par(lemsm_ctx* ctx, const host::pt* recs /* nw x (L+1) */, u32 nw, u32 L, std::vector<host::pt>& out) {
+  out.resize(nw);
+  host_parallel(ctx, (int)nw, [&](int w) { out[w] = window_sum<P64>(recs + (size_t)w * (L + 1), L); });
+}
+
 template <class P64>
 void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W window sums */, u64 out[12]) {
   typedef host::HG<P64> G;
@@ -931,24 +977,6 @@ void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W window sums */, 
   for (int w = (int)mp.W - 1; w >= 0; w--) {
     for (u32 k = 0; k < mp.c; k++) acc = G::dbl(acc);
     acc = G::add(acc, recs[w]);
-  }
-  G::to_jacobian(acc, out);
-}
-
-// Whole-MSM host tail straight from the per-window records [total, U_0..U_{L-1}]:
-//   sum_w 2^(cw) (total_w + sum_l 2^l U_{w,l}) = sum_j 2^j T_j  with  T_{cw+l} = U_{w,l} (+ total_w at l = 0),
-// one Horner pass of c(W-1)+L doublings instead of W separate L-step passes followed by a cW-step one
-// (l <= L-1 = c-2 < c, so the positions never collide).
-template <class P64>
-void msm_combine_raw_t(const MsmPlan& mp, const host::pt* recs /* W x (L+1) */, u64 out[12]) {
-  typedef host::HG<P64> G;
-  host::pt acc = G::identity();
-  for (int j = (int)(mp.c * (mp.W - 1) + mp.L) - 1; j >= 0; j--) {
-    acc = G::dbl(acc);
-    u32 w = (u32)j / mp.c, l = (u32)j % mp.c;
-    const host::pt* r = recs + (size_t)w * (mp.L + 1);
-    if (l < mp.L) acc = G::add(acc, r[1 + l]);
-    if (l == 0) acc = G::add(acc, r[0]);
   }
   G::to_jacobian(acc, out);
 }
@@ -973,10 +1001,8 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   std::vector<host::pt> recs;
   int rc = run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, recs);
   if (rc) return rc;
-  if (ctx->want_raw_records) { out.swap(recs); return LEMSM_OK; }   // whole-MSM entry: one fused Horner (msm_combine_raw_t)
   // this rank's share of the host tail: S_w = total + sum_l 2^l U_l for its own windows
-  out.resize(we - wb);
-  for (u32 w = 0; w < we - wb; w++) out[w] = window_sum<P64>(recs.data() + (size_t)w * (mp.L + 1), mp.L);
+  window_sums_par<P64>(ctx, recs.data(), we - wb, mp.L, out);
   return LEMSM_OK;
 }
 
@@ -1036,8 +1062,7 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   std::vector<host::pt> recs;
   rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, recs);
   if (rc) return rc;
-  out.resize(pe - pb);
-  for (u32 w = 0; w < pe - pb; w++) out[w] = window_sum<P64>(recs.data() + (size_t)w * (lp.L + 1), lp.L);
+  window_sums_par<P64>(ctx, recs.data(), pe - pb, lp.L, out);
   u32 err[2] = {0xffffffffu, 0};
   if (n) {
     HIPCHK(ctx, hipMemcpyAsync(err, dg.err, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1150,7 +1175,7 @@ int sharded_records(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u
   for (int r = 0; r < ex.world; r++) {
     u32 a, b; shard_range(W, ex.world, r, a, b);
     if (a == b) continue;
-    sum_slab_records<P64, G>(raw.data() + (size_t)r * sb, wr.out_slab, wr.nslabs, b - a, L, part);
+    sum_slab_records<P64, G>(ctx, raw.data() + (size_t)r * sb, wr.out_slab, wr.nslabs, b - a, L, part);
     std::copy(part.begin(), part.end(), all.begin() + (size_t)a * (L + 1));
   }
   return LEMSM_OK;
@@ -1166,7 +1191,9 @@ int msm_sharded_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   std::vector<host::pt> all;
   int rc = sharded_records<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, 0, d_points, ex, all);
   if (rc) return rc;
-  msm_combine_raw_t<P64>(mp, all.data(), out);
+  std::vector<host::pt> sums;
+  window_sums_par<P64>(ctx, all.data(), mp.W, mp.L, sums);
+  msm_combine_t<P64>(mp, sums.data(), out);
   return LEMSM_OK;
 }
 
@@ -1193,8 +1220,8 @@ int lhs_sharded_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
     if (bad_index) *bad_index = err[0];
     return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar out of range (>= isqrt(order)+2)");
   }
-  std::vector<host::pt> sums(lp.d);
-  for (u32 w = 0; w < lp.d; w++) sums[w] = window_sum<P64>(all.data() + (size_t)w * (lp.L + 1), lp.L);
+  std::vector<host::pt> sums;
+  window_sums_par<P64>(ctx, all.data(), lp.d, lp.L, sums);
   lhs_combine_t<P64>(lp, sums.data(), out_carry, out_carries);
   return LEMSM_OK;
 }
@@ -1413,6 +1440,8 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   if (ctx->stream_tail) { (void)hipStreamSynchronize(ctx->stream_tail); (void)hipStreamDestroy(ctx->stream_tail); }
   for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
   if (ctx->comm) { (void)Rccl::get().CommDestroy(ctx->comm); ctx->comm = nullptr; }
+  ctx->pool.reset();
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather, &ctx->dw_tab, &ctx->dw_arena, &ctx->dw_tmp}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -1429,7 +1458,8 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "binsort")) { if (value < 0) return LEMSM_ERR_BAD_ARG; ctx->opt_binsort = value; }
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
-  else if (!strcmp(name, "seg_records")) { if (value < 0 || value > 64 || value == 1) return LEMSM_ERR_BAD_ARG; ctx->opt_seg_records = value; }
+  else if (!strcmp(name, "merge_slice")) { if (value != 0 && (value < 33 || value > 65536)) return LEMSM_ERR_BAD_ARG; ctx->opt_merge_slice = value; }
+  else if (!strcmp(name, "merge_wave_th")) { if (value < 0 || value > (1 << 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_merge_wave_th = value; }
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 4 || value == 3) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
   else if (!strcmp(name, "xcd_windows")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_xcd_windows = value; }
@@ -1438,12 +1468,13 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "dw_fuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_fuse = value; }
   else if (!strcmp(name, "dw_wrap")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_wrap = value; }
   else if (!strcmp(name, "ntt_tiled")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_ntt_tiled = value; }
-  else if (!strcmp(name, "pyr_fuse")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_fuse = value; }
+  else if (!strcmp(name, "pyr_fuse")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_fuse = value; }
   else if (!strcmp(name, "validate_points")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_validate_points = value; }
   else if (!strcmp(name, "entry_ring")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_entry_ring = value; }
   else if (!strcmp(name, "slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_bits = value; }
   else if (!strcmp(name, "host_slab_bits")) { if (value != 0 && (value < 12 || value > 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_host_slab_bits = value; }
   else if (!strcmp(name, "accum_waves")) { if (value != 0 && (value < 2 || value > 4)) return LEMSM_ERR_BAD_ARG; ctx->opt_accum_waves = value; }
+  else if (!strcmp(name, "host_threads")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_host_threads = value; ctx->pool.reset(); }
   else if (!strcmp(name, "field")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_field = value; }
   else return LEMSM_ERR_BAD_ARG;
   return LEMSM_OK;
@@ -1502,13 +1533,13 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (!(ctx->host_stage && ctx->host_stage->h_points)) { rc = validate_points(ctx, curve, d_points, n); if (rc) return rc; }
   MsmPlan mp = make_msm_plan(ctx, curve, n);
-  std::vector<host::pt> recs;
-  ctx->want_raw_records = true;
-  rc = msm_partial_dispatch(ctx, curve, d_scalars, d_points, n, 0, mp.W, recs);
-  ctx->want_raw_records = false;
+  // host tail: the W window sums in parallel (hostpool.hpp, inside msm_partial_t), then the serial Horner over the
+  // windows (c (W - 1) doublings)
+  std::vector<host::pt> sums;
+  rc = msm_partial_dispatch(ctx, curve, d_scalars, d_points, n, 0, mp.W, sums);
   if (rc) return rc;
-  if (curve == LEMSM_BN254_G1) msm_combine_raw_t<host::FqParams64>(mp, recs.data(), out);
-  else msm_combine_raw_t<host::FrParams64>(mp, recs.data(), out);
+  if (curve == LEMSM_BN254_G1) msm_combine_t<host::FqParams64>(mp, sums.data(), out);
+  else msm_combine_t<host::FrParams64>(mp, sums.data(), out);
   return LEMSM_OK;
 }
 

@@ -129,12 +129,12 @@ struct XYZZ {
 
   static __device__ __forceinline__ void neg(pt& p) { F::neg(p.y, p.y); }
 
-  // lane i receives lane (i - d)'s point (wave64)
-  static __device__ __forceinline__ void shfl_up(pt& r, const pt& p, int d) {
+  // every lane receives lane `src`'s point (wave64; src may differ per lane)
+  static __device__ __forceinline__ void shfl(pt& r, const pt& p, int src) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      r.x.v[i] = __shfl_up(p.x.v[i], d); r.y.v[i] = __shfl_up(p.y.v[i], d);
-      r.zz.v[i] = __shfl_up(p.zz.v[i], d); r.zzz.v[i] = __shfl_up(p.zzz.v[i], d);
+      r.x.v[i] = __shfl(p.x.v[i], src); r.y.v[i] = __shfl(p.y.v[i], src);
+      r.zz.v[i] = __shfl(p.zz.v[i], src); r.zzz.v[i] = __shfl(p.zzz.v[i], src);
     }
   }
 

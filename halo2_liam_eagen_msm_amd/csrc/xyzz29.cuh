@@ -202,12 +202,12 @@ struct XYZZ29 {
     F::mul(t, acc.zzz, q.zzz); F::mul(acc.zzz, t, PPP);
   }
 
-  // lane i receives lane (i - d)'s point (wave64)
-  static __device__ __forceinline__ void shfl_up(pt& r, const pt& p, int d) {
+  // every lane receives lane `src`'s point (wave64; src may differ per lane)
+  static __device__ __forceinline__ void shfl(pt& r, const pt& p, int src) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-      r.x.l[i] = __shfl_up(p.x.l[i], d); r.y.l[i] = __shfl_up(p.y.l[i], d);
-      r.zz.l[i] = __shfl_up(p.zz.l[i], d); r.zzz.l[i] = __shfl_up(p.zzz.l[i], d);
+      r.x.l[i] = __shfl(p.x.l[i], src); r.y.l[i] = __shfl(p.y.l[i], src);
+      r.zz.l[i] = __shfl(p.zz.l[i], src); r.zzz.l[i] = __shfl(p.zzz.l[i], src);
     }
   }
 

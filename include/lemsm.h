@@ -95,11 +95,13 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    "host_slab_bits" (host-pointer entries: log2 of the slab of pairs uploaded while the previous
    slab is being accumulated; 0 = auto = 21), "slab_bits" (device-pointer entries: log2 of the
    slab of pairs one pass of the pipeline covers; 0 = auto = 24, smaller values are a test knob),
-   "seg_records" (edge records per thread at the first reduction level, 0 = auto = 8),
+   "merge_slice" (edge-record merge: pieces of a long bucket one wave adds, 0 = auto = 512; small values are a
+   test knob), "merge_wave_th" (buckets of 9..32 pieces get one wave each while there are fewer than this many,
+   0 = auto = 2049; 1 = always serial),
    "abi_points" (lazy arithmetic: 1 = convert the points to the kernels' domain in a pass of their
    own, 2 = let the accumulation consume them as passed in, 0 = choose by segment length and window
-   count), "pyr_fuse" (0 = the narrow last steps of the bucket-reduction pyramid run in one launch, 1 = one launch per
-   step: A/B knob), "ntt_tiled" (divisor witness: 0 = LDS-tiled transforms, up to 10 stages per launch; 2 = one launch per
+   count), "pyr_fuse" (0 = one launch per step of the bucket-reduction pyramid, 2 = the narrow last steps in one launch of one
+   block per window: A/B knob, measured slower), "host_threads" (host tail: 0 = up to 8 threads, 1 = serial), "ntt_tiled" (divisor witness: 0 = LDS-tiled transforms, up to 10 stages per launch; 2 = one launch per
    stage: A/B knob), "dw_kb" (divisor witness: slots per thread of the batched-inversion kernels, 8..64; 0 = auto),
    "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
    input from the coefficient arrays and the last inverse pass scatters into them; 2 = separate load / store kernels:

@@ -296,7 +296,7 @@ def test_msm_device_entry_multi_slab(fctx, groups):
         ctx.set_option("slab_bits", 0); ctx.set_option("groups", 0)
 
 
-@pytest.mark.parametrize("n,opts,host", [(130972, {"slab_bits": 16, "seg_records": 2}, False), (262017, {"host_slab_bits": 16, "seg_records": 2}, True),
+@pytest.mark.parametrize("n,opts,host", [(130972, {"slab_bits": 16, "merge_slice": 33}, False), (262017, {"host_slab_bits": 16, "merge_wave_th": 1}, True),
                                          ((1 << 19) + 60000, {}, True)],
                          ids=["device-2^16-slabs-ragged-last", "host-2^16-slabs-ragged-last", "host-default-slabs-last-slab-below-2^16"])
 def test_msm_ragged_last_slab_workspace(ctx, n, opts, host):
