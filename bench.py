@@ -189,6 +189,7 @@ def main():
         if ck > 0:
             clock_sum += ck; clock_n += 1
     clock_mhz = clock_sum / clock_n if clock_n else 0.0
+    merge_counts = ctx.last_merge_counts()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -255,6 +256,7 @@ def main():
         # bit_exact is derived from checks that ran in THIS process (each raises on a mismatch); null when none did
         if args.option:
             out["config"]["options"] = args.option
+        out["config"]["merge_queues"] = {"short_3to8": merge_counts[0], "medium_9to32": merge_counts[1], "long_slices": merge_counts[2], "multi_slice_buckets": merge_counts[3]}
         out["config"]["bit_exact"] = True if checks else None
         out["config"]["bit_exact_checks"] = checks
         print(json.dumps(out), flush=True)

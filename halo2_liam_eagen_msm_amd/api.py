@@ -202,6 +202,13 @@ class Context:
         self._check(self.lib.lemsm_last_timing(self.h, out))
         return out[0], out[1], int(out[2])
 
+    def last_merge_counts(self) -> Tuple[int, int, int, int]:
+        """edge-record merge of the last MSM call: buckets queued as short (3..8 pieces), medium (9..32), slices of
+        long ones, multi-slice buckets (test / profiling aid)"""
+        out = (ctypes.c_uint64 * 4)()
+        self._check(self.lib.lemsm_debug_last_merge_counts(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def last_accum_clock_mhz(self) -> float:
         """shader clock (MHz) the accumulate kernel of the last MSM call sustained (in-kernel stamps)"""
         out = ctypes.c_double()

@@ -157,16 +157,16 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
 // STARTS in owns it (rec_key[ta] = key).
 //   k_merge_pairs   one thread per chunk: a two-piece bucket (the common case: uniform digits put about one
 //                   bucket boundary into every chunk) is added and stored at once; longer ones are queued by size.
-//   k_merge_queues  3..8 pieces: one thread per queued bucket, serial.  9..32 pieces: one wave per bucket while
-//                   the queue is short (latency), else serial like the short ones (throughput).  More than 32:
-//                   slices of <= `slice` pieces, one wave each (lanes stride over the pieces, then a shuffle
-//                   tree); a bucket of several slices leaves one partial sum per slice.
+//   k_merge_serial  3..8 pieces: one thread per queued bucket, serial (and 9..32 pieces when that queue is long).
+//   k_merge_waves   9..32 pieces: one wave per bucket while the queue is short (latency).  More than 32: slices of
+//                   <= `slice` pieces, one wave each (lanes stride over the pieces, then a DPP scan); a bucket of
+//                   several slices leaves one partial sum per slice.
 //   k_merge_final   one wave per multi-slice bucket adds its partials.
 // Depth: 1 addition for uniform scalars (was 8 + 4 x 6 through the segmented-scan levels), <= slice/64 + 6 + 6
 // for any input; the sum of a bucket is formed in piece order whatever the queue order, so results are
 // deterministic.
 // ------------------------------------------------------------------------------------
-enum { MQ_S = 0, MQ_M = 1, MQ_L = 2, MQ_F = 3, MQ_P = 4, MQ_WORDS = 8 };   // queue counters: short, medium, long slices, multi-slice buckets, partials
+enum { MQ_S = 0, MQ_M = 1, MQ_L = 2, MQ_F = 3, MQ_P = 4, MQ_WORDS = 16 /* [8..15]: debug cycle stamps of the wave kernels */ };   // queue counters: short, medium, long slices, multi-slice buckets, partials
 struct MqLayout { u32 offS, offM, offL, offF, capS, capM, capL, capF, capP, slice, wave_th; };
 static const u32 MQ_DST_BUCKET = 0xffffffffu;
 
@@ -225,81 +225,116 @@ __global__ __launch_bounds__(256) void k_merge_pairs(GroupPlan pl, u32 scaled, M
   }
 }
 
-// lane 0 of the wave ends up with the sum of the lanes' points (lanes >= nact hold the identity)
-template <class G>
-__device__ __forceinline__ void merge_wave_tree(typename G::pt& acc, u32 lane, u32 nact) {
+// One wave adds the pieces [t0, t0 + n) of a bucket (FROM_PARTIALS: the partial sums [t0, t0 + n) of its slices): the lanes
+// stride over them, then a DPP scan (G::scan_fetch) leaves the sum in lane `result_lane`.  For n < 64 the pieces are
+// replicated with period m = the power of two >= n, so that every lane carries real work (a sparsely populated wave
+// runs its additions 1.7-3x slower) and the scan stops at the steps that stay inside one replica.  Serial phase and scan
+// share ONE call site of G::add (a second inlined copy of the ~25 KB addition buys nothing and costs instruction cache).
+template <class G, bool FROM_PARTIALS>
+__device__ __forceinline__ u32 merge_wave_sum(typename G::pt& acc, u32 lane, u32 n, u32 t0, u32 lf, u32 scaled,
+                                              const char* __restrict__ src, u32 cap) {
+  G::set_identity(acc);
+  u32 m = 1; while (m < n && m < 64u) m <<= 1;
+  const u32 nser = (n + 63u) >> 6;
+  const u32 nscan = m <= 16u ? (u32)__builtin_ctz(m) : (m == 32u ? 5u : 6u);   // row steps with a shift below m, then the row broadcasts
 #pragma unroll 1
-  for (u32 d = 32; d >= 1; d >>= 1) {
-    if (d >= nact) continue;                      // wave-uniform: nothing lives at lane >= d yet
-    typename G::pt q; G::shfl(q, acc, (int)((lane + d) & 63u));
-    if (lane >= d || lane + d >= nact) G::set_identity(q);
+  for (u32 s = 0; s < nser + nscan; s++) {
+    typename G::pt q;
+    if (s < nser) {
+      const u32 j = (lane & (m - 1u)) + 64u * s;
+      if (j < n) {
+        if constexpr (FROM_PARTIALS) { if (t0 + j < cap) G::load(q, src + (size_t)(t0 + j) * G::PT_BYTES); else G::set_identity(q); }
+        else merge_load_piece<G>(q, src, t0 + j, j + 1 == n && lf, scaled);
+      } else G::set_identity(q);
+    } else {
+      G::scan_fetch(q, acc, (int)(s - nser));
+    }
     G::add(acc, q);
   }
+  return m - 1u;
 }
 
+// One block per CU: the wave kernels below are latency chains (a slice is <= slice/64 + 6 dependent additions), and the
+// dispatcher is free to stack several 256-thread blocks on one CU while others idle -- measured: 968 slices on 242
+// blocks ran in 198 us where one wave's chain takes 98.  A static LDS footprint above half the CU's 160 KB pins one
+// block per CU, i.e. one wave per SIMD; more items than resident waves are taken in turns by the same waves.
+static const u32 MERGE_LDS_PAD_WORDS = 21504;    // 84 KB
+
+// 3..8 pieces (and 9..32 when that queue is long): one lane per queued bucket, 64 buckets per wave-sized chunk; the two
+// classes start on chunk boundaries so that a wave's trip counts are alike.  One block per CU; chunk c goes to block
+// c mod gridDim.x, so a short queue spreads over the CUs one wave each instead of filling a few CUs' wave slots.
 template <class G>
-__global__ __launch_bounds__(256) void k_merge_queues(u32 nblk_short, u32 scaled, MqLayout lay, const u32* __restrict__ mq_cnt,
+__global__ __launch_bounds__(256) void k_merge_serial(u32 scaled, MqLayout lay, const u32* __restrict__ mq_cnt,
                                                       const uint4* __restrict__ mq_items, const char* __restrict__ rec_pt,
-                                                      char* __restrict__ partial, char* __restrict__ bucket_sum) {
-  const u32 cS = min(mq_cnt[MQ_S], lay.capS), cMall = min(mq_cnt[MQ_M], lay.capM), cL = min(mq_cnt[MQ_L], lay.capL);
-  const bool m_serial = cMall > lay.wave_th;
-  if (blockIdx.x < nblk_short) {
-    // one thread per queued bucket; the two classes start on wave boundaries so that a wave's trip counts are alike
-    const u32 v = blockIdx.x * 256 + threadIdx.x;
-    const u32 rS = (cS + 63u) & ~63u, cM = m_serial ? cMall : 0u;
-    uint4 it;
-    if (v < rS) { if (v >= cS) return; it = mq_items[lay.offS + v]; }
-    else { if (v - rS >= cM) return; it = mq_items[lay.offM + (v - rS)]; }
-    const u32 key = it.x, t0 = it.y, n = it.z & 0x7fffffffu, lf = it.z >> 31;
-    typename G::pt acc, q;
-    merge_load_piece<G>(acc, rec_pt, t0, false, scaled);
+                                                      char* __restrict__ bucket_sum) {
+  __shared__ u32 pad_[MERGE_LDS_PAD_WORDS];
+  if (scaled > 1) pad_[threadIdx.x] = scaled;     // never true: keeps the allocation (one block per CU, above)
+  const u32 cS = min(mq_cnt[MQ_S], lay.capS), cMall = min(mq_cnt[MQ_M], lay.capM);
+  const u32 cM = cMall > lay.wave_th ? cMall : 0u;
+  const u32 chS = (cS + 63u) >> 6, chM = (cM + 63u) >> 6;
+  const u32 lane = threadIdx.x & 63u;
 #pragma unroll 1
-    for (u32 j = 1; j < n; j++) {
+  for (u32 c = blockIdx.x + gridDim.x * (threadIdx.x >> 6); c < chS + chM; c += gridDim.x * 4u) {
+    uint4 it;
+    if (c < chS) { const u32 v = 64u * c + lane; if (v >= cS) continue; it = mq_items[lay.offS + v]; }
+    else { const u32 v = 64u * (c - chS) + lane; if (v >= cM) continue; it = mq_items[lay.offM + v]; }
+    const u32 key = it.x, t0 = it.y, n = it.z & 0x7fffffffu, lf = it.z >> 31;
+    typename G::pt acc, q; G::set_identity(acc);
+#pragma unroll 1
+    for (u32 j = 0; j < n; j++) {
       merge_load_piece<G>(q, rec_pt, t0 + j, j + 1 == n && lf, scaled);
       G::add(acc, q);
     }
     if (scaled) G::scale(acc);
     G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc);
-    return;
   }
-  // one wave per medium bucket / per slice of a long one
+}
+
+// 9..32 pieces (while that queue is short) and the slices of longer buckets: one wave per item
+template <class G>
+__global__ __launch_bounds__(256) void k_merge_waves(u32 scaled, MqLayout lay, const u32* __restrict__ mq_cnt,
+                                                     const uint4* __restrict__ mq_items, const char* __restrict__ rec_pt,
+                                                     char* __restrict__ partial, char* __restrict__ bucket_sum, u32* __restrict__ dbg) {
+  __shared__ u32 pad_[MERGE_LDS_PAD_WORDS];
+  if (scaled > 1) pad_[threadIdx.x] = scaled;     // never true: keeps the allocation
+  const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+  const u32 cMall = min(mq_cnt[MQ_M], lay.capM), cL = min(mq_cnt[MQ_L], lay.capL);
   const u32 lane = threadIdx.x & 63u;
-  const u32 nwaves = (gridDim.x - nblk_short) * 4u;
-  const u32 cM = m_serial ? 0u : cMall;
+  const u32 nwaves = gridDim.x * 4u;
+  const u32 cM = cMall > lay.wave_th ? 0u : cMall;
 #pragma unroll 1
-  for (u32 w = (blockIdx.x - nblk_short) * 4u + (threadIdx.x >> 6); w < cM + cL; w += nwaves) {
+  for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < cM + cL; w += nwaves) {
     const uint4 it = w < cM ? mq_items[lay.offM + w] : mq_items[lay.offL + (w - cM)];
-    const u32 key = it.x, t0 = it.y, n = it.z & 0x7fffffffu, lf = it.z >> 31, dst = it.w;
-    typename G::pt acc, q; G::set_identity(acc);
-#pragma unroll 1
-    for (u32 j = lane; j < n; j += 64) {
-      merge_load_piece<G>(q, rec_pt, t0 + j, j + 1 == n && lf, scaled);
-      G::add(acc, q);
-    }
-    merge_wave_tree<G>(acc, lane, min(n, 64u));
-    if (lane == 0) {
+    const u32 key = it.x, dst = it.w;
+    typename G::pt acc;
+    const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+    const u32 rl = merge_wave_sum<G, false>(acc, lane, it.z & 0x7fffffffu, it.y, it.z >> 31, scaled, rec_pt, 0);
+    const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
+    if (lane == rl) {
       if (dst == MQ_DST_BUCKET) { if (scaled) G::scale(acc); G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc); }
       else if (dst < lay.capP) G::store(partial + (size_t)dst * G::PT_BYTES, acc);      // plain form
     }
+    if (dbg && w == 0 && lane == 0) { dbg[8] = (u32)(tk1 - tk0); dbg[9] = (u32)(tk2 - tk1); dbg[10] = (u32)(__builtin_amdgcn_s_memtime() - tk2); dbg[11] = it.z; }
   }
 }
 
 template <class G>
 __global__ __launch_bounds__(256) void k_merge_final(u32 scaled, MqLayout lay, const u32* __restrict__ mq_cnt, const uint4* __restrict__ mq_items,
-                                                     const char* __restrict__ partial, char* __restrict__ bucket_sum) {
+                                                     const char* __restrict__ partial, char* __restrict__ bucket_sum, u32* __restrict__ dbg) {
+  __shared__ u32 pad_[MERGE_LDS_PAD_WORDS];
+  if (scaled > 1) pad_[threadIdx.x] = scaled;     // never true: one block per CU (see k_merge_waves)
+  const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
   const u32 cF = min(mq_cnt[MQ_F], lay.capF);
   const u32 lane = threadIdx.x & 63u, nwaves = gridDim.x * 4u;
 #pragma unroll 1
   for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < cF; w += nwaves) {
     const uint4 it = mq_items[lay.offF + w];
-    const u32 key = it.x, p0 = it.y, n = it.z;
-    typename G::pt acc, q; G::set_identity(acc);
-#pragma unroll 1
-    for (u32 j = lane; j < n; j += 64) {
-      if (p0 + j < lay.capP) { G::load(q, partial + (size_t)(p0 + j) * G::PT_BYTES); G::add(acc, q); }
-    }
-    merge_wave_tree<G>(acc, lane, min(n, 64u));
-    if (lane == 0) { if (scaled) G::scale(acc); G::store(bucket_sum + (size_t)key * G::PT_BYTES, acc); }
+    typename G::pt acc;
+    const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+    const u32 rl = merge_wave_sum<G, true>(acc, lane, it.z, it.y, 0, 0, partial, lay.capP);
+    const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
+    if (lane == rl) { if (scaled) G::scale(acc); G::store(bucket_sum + (size_t)it.x * G::PT_BYTES, acc); }
+    if (dbg && w == 0 && lane == 0) { dbg[12] = (u32)(tk1 - tk0); dbg[13] = (u32)(tk2 - tk1); dbg[14] = (u32)(__builtin_amdgcn_s_memtime() - tk2); dbg[15] = it.z; }
   }
 }
 
@@ -344,6 +379,119 @@ __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tas
   PyrTask tk = tasks[ti];
   if (i >= tk.count) return;
   pyr_item<G>(tk, w, i, arena);
+}
+
+// Steps 1 and 2 of the pyramid in one pass over the bucket sums.  A step-per-launch pyramid moves every point of a level
+// through HBM twice (written by one launch, read by the next) and its first steps are as much bandwidth- as
+// arithmetic-bound (step 1 of a 2^24-point MSM: 354 MB in 111 us); the first two steps are 3/4 of all the additions.
+// Here one thread owns 8 consecutive buckets b0..b7 of a window and leaves exactly what steps 1 + 2 of the task tables
+// leave -- A^2[2i], A^2[2i+1], stage 2 of U_0's partial sums and stage 1 of U_1's -- without ever storing A^1:
+//   a10 = b0+b1  a11 = b2+b3  a12 = b4+b5  a13 = b6+b7      A^2[2i] = a10+a11   A^2[2i+1] = a12+a13
+//   U_0: (b1+b3) + (b5+b7)                                    U_1: a11 + a13
+// 10 additions for 8 + 3 loads and 4 + 2 stores (the two launches: 10 additions, 14 loads, 7 stores).  The ten additions
+// run through ONE call site of G::add: the body is a ten-step program over three named point registers, operands
+// fetched and results filed by a switch on the step (an inlined copy per addition would be ~300 KB of code).  Empty buckets are
+// recognised from bucket_start[], so bucket_sum[] needs no zero fill.
+struct PyrFirst2Args {
+  u32 nwin, nb, nbw, nbp;            // windows of the group, buckets per window, key stride of a window, padded bucket count
+  u32 bucket_off, a2_off, r02_off, r11_off, wstride;   // arena offsets in points; A^2 / R regions have window stride nbp
+  u32 scaled;                        // bucket sums are in k_accum1's (X, Y, 32 ZZ, 32 ZZZ) form
+};
+
+template <class G>
+__global__ __launch_bounds__(256, 1) void k_pyramid_first2(PyrFirst2Args a, const u32* __restrict__ bucket_start, char* __restrict__ arena, u32* __restrict__ dbg) {
+  const unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+  const u32 gid = blockIdx.x * 256 + threadIdx.x;
+  const u32 per_win = a.nbp >> 3;
+  const u32 w = gid / per_win, i = gid - w * per_win;
+  if (w >= a.nwin) return;
+  const u32 key0 = w * a.nbw + 8u * i;                     // first of this thread's 8 keys
+  // Three named point registers only: with the addition's own ~135 VGPRs a fourth would push the kernel past the 256
+  // architectural registers and the allocator then shuffles points through AGPRs around every addition (measured: +40 %
+  // instructions).  The two long-lived values -- r = b1+b3 and a11 -- wait in their own output slots (U_0's and U_1's)
+  // and are read back when their partners exist: two 160-byte round trips through L2 per thread.
+  //   step      0       1        2        3        4       5        6        7       8        9
+  //   x      ld b0   ld b2       B        A     ld b4      D    ld r02    ld b6      A     ld r11
+  //   y      ld b1   ld b3       D     ld r11   ld b5   ld b7      D      ld b7      B        B
+  //   keep   B = b1  D = b3                     D = b5
+  //   result A = a10 st r11   st r02   st A2    A = a12  D = r'  st r02   B = a13  st A2'  st r11
+  typename G::pt A, B, D, x, y;
+  G::set_identity(A); G::set_identity(B); G::set_identity(D);
+  const size_t o_a2 = (size_t)a.a2_off + (size_t)w * a.wstride + 2u * i;
+  const size_t o_r02 = (size_t)a.r02_off + (size_t)w * a.wstride + i, o_r11 = (size_t)a.r11_off + (size_t)w * a.wstride + i;
+  // Memory operands -- a bucket (index < 8; empty / out-of-window ones read as the identity, the ABI form is unscaled) or a
+  // point of the arena (this thread's own earlier store) -- are requested one step ahead as raw 16-byte words, so that
+  // their latency (~4 us a round trip on cold data, with one wave per SIMD nothing else hides it: measured 38 % of the
+  // kernel) passes behind the previous addition.  Bucket loads are unconditional (the address is inside the arena whatever
+  // the key) and masked by `have` when consumed: the first operands leave together with the bucket_start[] reads.
+  auto operands = [&](u32 step, u32& kx, u32& ky, size_t& tx, size_t& ty) {
+    kx = 8; ky = 8; tx = ~(size_t)0; ty = ~(size_t)0;
+    switch (step) {
+      case 0: kx = 0; ky = 1; break;
+      case 1: kx = 2; ky = 3; break;
+      case 3: ty = o_r11; break;
+      case 4: kx = 4; ky = 5; break;
+      case 5: ky = 7; break;
+      case 6: tx = o_r02; break;
+      case 7: kx = 6; ky = 7; break;
+      case 9: tx = o_r11; break;
+      default: break;
+    }
+    if (kx < 8) tx = (size_t)a.bucket_off + key0 + kx;
+    if (ky < 8) ty = (size_t)a.bucket_off + key0 + ky;
+  };
+  uint4 rx[G::RAW_WORDS], ry[G::RAW_WORDS];
+  {
+    u32 kx, ky; size_t tx, ty; operands(0, kx, ky, tx, ty);
+    G::load_raw(rx, arena + tx * G::PT_BYTES); G::load_raw(ry, arena + ty * G::PT_BYTES);
+  }
+  u32 have = 0;
+#pragma unroll
+  for (u32 k = 0; k < 8; k++)
+    if (8u * i + k < a.nb && bucket_start[key0 + k + 1] != bucket_start[key0 + k]) have |= 1u << k;
+#pragma unroll 1
+  for (u32 step = 0; step < 10; step++) {
+    {
+      u32 kx, ky; size_t tx, ty; operands(step, kx, ky, tx, ty);
+      if (tx != ~(size_t)0) { G::from_raw(x, rx); if (kx < 8) { if (!((have >> kx) & 1u)) G::set_identity(x); else if (a.scaled) G::unscale(x); } }
+      if (ty != ~(size_t)0) { G::from_raw(y, ry); if (ky < 8) { if (!((have >> ky) & 1u)) G::set_identity(y); else if (a.scaled) G::unscale(y); } }
+      if (step < 9) {
+        operands(step + 1, kx, ky, tx, ty);
+        if (tx != ~(size_t)0) G::load_raw(rx, arena + tx * G::PT_BYTES);
+        if (ty != ~(size_t)0) G::load_raw(ry, arena + ty * G::PT_BYTES);
+      }
+    }
+    switch (step) {
+      case 0: B = y; break;
+      case 1: D = y; break;
+      case 2: x = B; y = D; break;
+      case 3: x = A; break;
+      case 4: D = y; break;
+      case 5: x = D; break;
+      case 6: y = D; break;
+      case 8: x = A; y = B; break;
+      case 9: y = B; break;
+      default: break;
+    }
+    const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+    G::add(x, y);
+    if (dbg && gid == 0) { if (step == 2) dbg[8] = (u32)(__builtin_amdgcn_s_memtime() - ta0); if (step == 0) dbg[9] = (u32)(__builtin_amdgcn_s_memtime() - tk0); }
+    size_t dst = ~(size_t)0;
+    switch (step) {
+      case 0: A = x; break;
+      case 1: dst = o_r11; break;
+      case 2: dst = o_r02; break;
+      case 3: dst = o_a2; break;
+      case 4: A = x; break;
+      case 5: D = x; break;
+      case 6: dst = o_r02; break;
+      case 7: B = x; break;
+      case 8: dst = o_a2 + 1; break;
+      default: dst = o_r11; break;
+    }
+    if (dst != ~(size_t)0) G::store(arena + dst * G::PT_BYTES, x);
+  }
+  if (dbg && gid == 0) { dbg[10] = (u32)(__builtin_amdgcn_s_memtime() - tk0); dbg[11] = (u32)(__builtin_amdgcn_s_memrealtime() - tr0); }
 }
 
 // The last steps of the pyramid in ONE launch: from the step where a window's whole step fits a few passes of one

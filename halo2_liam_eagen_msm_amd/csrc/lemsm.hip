@@ -49,9 +49,11 @@ const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUN
 // heavy kernels are instantiated in inst_*.hip
 #define LEMSM_EXTERN_G(G)                                                                                   \
   extern template __global__ void lemsm::k_merge_pairs<G>(GroupPlan, u32, MqLayout, const u32*, const u32*, const u32*, const char*, char*, u32*, uint4*); \
-  extern template __global__ void lemsm::k_merge_queues<G>(u32, u32, MqLayout, const u32*, const uint4*, const char*, char*, char*); \
-  extern template __global__ void lemsm::k_merge_final<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*); \
+  extern template __global__ void lemsm::k_merge_serial<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*); \
+  extern template __global__ void lemsm::k_merge_waves<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*, char*, u32*); \
+  extern template __global__ void lemsm::k_merge_final<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*, u32*); \
   extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*); \
+  extern template __global__ void lemsm::k_pyramid_first2<G>(PyrFirst2Args, const u32*, char*, u32*); \
   extern template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*);
 #define LEMSM_EXTERN_ACC(G, W) \
   extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
@@ -88,11 +90,12 @@ struct HostStage { const uint8_t* h_scalars; const void* h_points; char* d_scala
 
 struct lemsm_ctx {
   int device = 0;
+  u32 num_cus = 256;                   // hipDeviceProp_t::multiProcessorCount (grids of the one-block-per-CU kernels)
   hipStream_t stream = nullptr;        // accumulate stream (and everything single-stream)
   hipStream_t stream_sort = nullptr;   // digit + sort passes of the next window group (high priority)
   hipStream_t stream_tail = nullptr;   // edge-record levels + pyramid of the previous group
   std::vector<hipEvent_t> evpool;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [4]: the digit pass's error words have reached the host
   DevBuf ws;        // workspace arena
   DevBuf in_s;      // staged scalars (host-pointer entries)
   DevBuf in_p;      // staged points
@@ -104,15 +107,19 @@ struct lemsm_ctx {
   double dw_phase_ms[4] = {0, 0, 0, 0};   // lhs witness: MSM core, point lists, merge forest, coefficient download
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
+  u32* h_small = nullptr;                        // 256 pinned bytes: error words of the negabase digit pass
   void* h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for the read-back of one call's records (one async copy, no pageable bounce)
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
   long opt_host_threads = 0;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
   double t_total_ms = 0, t_accum_ms = 0; int n_accum = 0;
+  double host_us[4] = {0, 0, 0, 0};                // last call, host tail: wait for the device, record conversion, window sums, final Horner
+  uint32_t dbg_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last group's in-kernel cycle stamps of the merge wave kernels (debug)
+  uint64_t dbg_merge[4] = {0, 0, 0, 0};            // last call: buckets the edge-record merge queued as short / medium / long slices / multi-slice
   double accum_clock_mhz = 0;                     // shader clock the accumulate kernel of the last call sustained (in-kernel stamps)
   size_t bad_index = 0;
   size_t truncated = 0;                          // scalars of the last negabase pass whose expansion needed more than d digits
@@ -349,6 +356,7 @@ struct GroupWs {
   u32* rec_key; char* rec_pt;      // k_accum1's pieces: the bucket a chunk owns, and its first / last partial sums (2 slots per chunk)
   u32* mq_cnt; uint4* mq_items; char* mq_partial; MqLayout mq;   // merge queues (kernels_ec.cuh)
   size_t zero_begin, zero_bytes;   // contiguous region to memset(0) per group (offset from base)
+  size_t zero_bytes_counters;      // ... its leading part: everything but the bucket sums
   size_t total;
   std::vector<size_t> guards;      // option ws_canary: offsets of the 256-byte guard behind every sub-buffer
 };
@@ -387,6 +395,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, const MqLa
   size_t o_bcount = take((size_t)NBpad * 4), o_bcursor = take((size_t)NBpad * 4);
   size_t o_arena = take((size_t)ar.total_points * ptb);
   size_t zend = o_arena + (size_t)NBpad * ptb;   // only the bucket sums need zeroing
+  w.zero_bytes_counters = o_arena - z0;
   size_t o_bin_start = take((MAX_BINS + 1) * 4), o_tile_prefix = take((MAX_BINS + 1) * 4), o_meta = take(64);
   size_t o_bstart = take(((size_t)NBpad + 1) * 4);
   size_t o_blockc = take((size_t)pl.nblk1 * pl.nbins * 8);   // per (window, range, bin): counts, then the offsets claimed inside the bin
@@ -521,12 +530,25 @@ struct NegProvider {
   }
 };
 
+// The group's results leave its (reused) workspace in ONE small launch: the per-window records -> the call's record area,
+// the digit pass's error words, k_accum1's clock stamps and the merge queue lengths -> the group's 64-byte status slot.
+__global__ __launch_bounds__(256) void k_group_finish(const uint4* __restrict__ out_area, uint4* __restrict__ d_out, u32 n16,
+                                                      const u32* __restrict__ err, const u32* __restrict__ clock, const u32* __restrict__ mq_cnt,
+                                                      u32* __restrict__ slot) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) d_out[i] = out_area[i];
+  if (blockIdx.x == 0 && threadIdx.x < 24) {
+    const u32 k = threadIdx.x;
+    slot[k] = k < 2 ? err[k] : (k < 4 ? 0u : (k < 12 ? clock[k - 4] : (k < 16 ? mq_cnt[k - 12] : mq_cnt[k - 8])));   // [16..23] = debug stamps mq_cnt[8..15]
+  }
+}
+
 // Runs one window group [w0,w1): sort + accumulate + reduce; results (gw x (L+1) XYZZ points)
 // are left in the arena's out area and copied to d_out (device) + gslot.
 template <class G, class Prov>
 int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
               bool abi /* d_points are in the C ABI's domain: k_accum1<.., true>, scaled outputs */,
-              char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, hipStream_t s_sort, hipStream_t s_acc,
+              char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, u32* d_slot /* device, this (slab, group)'s 64-byte status slot */, hipStream_t s_sort, hipStream_t s_acc,
               hipStream_t s_tail, hipEvent_t ev_sorted, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
   // Three queues: the sort passes of this group may run while the previous group accumulates
   // (s_sort), the accumulate kernels of all groups run back to back (s_acc), and this group's
@@ -561,7 +583,9 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   if (pl.nbins > MAX_BINS || pl.BW > BW_MAX || pl.LB > MAX_LB || pl.spb > 4 * STAGE || (pl.c && pl.dstride < pl.n) || pl.T2 > STAGE2 || pl.bin_cap > BIN_CAP)
     return fail(ctx, LEMSM_ERR_HIP, "internal: window-group plan exceeds a kernel limit (bins " + std::to_string(pl.nbins) + ", bins per window " + std::to_string(pl.BW) + ")");
 
-  HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, w.zero_bytes, st));
+  // k_pyramid_first2 recognises empty buckets from bucket_start[]: with it only the counters are zeroed, not the bucket sums
+  const bool first2 = L >= 5 && ctx->opt_pyr_first2 == 1;
+  HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, first2 ? w.zero_bytes_counters : w.zero_bytes, st));
   for (size_t g : w.guards) HIPCHK(ctx, hipMemsetAsync(ws_base + g, 0xA5, WS_GUARD, st));
 
   typename Prov::Dec dec;
@@ -620,25 +644,36 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     const u32 sc = abi ? 1u : 0u;
     char* bsum = w.arena + (size_t)ar.bucket_off * ptb;
     hipLaunchKernelGGL((k_merge_pairs<G>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, sc, mq, d_bstart, w.meta, w.rec_key, w.rec_pt, bsum, w.mq_cnt, w.mq_items);
-    // grid of the queue kernel: the host does not know the queue lengths, so the serial part gets the bound of its two
-    // classes (blocks past the counts exit at once) and the wave part a fixed number of waves that stride over the items
-    const u32 nblk_short = (mq.capS + mq.capM + 64 + 255) / 256;
-    const u32 nblk_wave = std::min(512u, std::max(1u, (mq.capM + mq.capL + 3) / 4));
-    hipLaunchKernelGGL((k_merge_queues<G>), dim3(nblk_short + nblk_wave), dim3(256), 0, st, nblk_short, sc, mq, w.mq_cnt, w.mq_items, w.rec_pt, w.mq_partial, bsum);
-    hipLaunchKernelGGL((k_merge_final<G>), dim3(std::min(64u, std::max(1u, (mq.capF + 3) / 4))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.mq_partial, bsum);
+    // the host does not know the queue lengths: these kernels run one block per CU whose waves take the items in turns
+    hipLaunchKernelGGL((k_merge_serial<G>), dim3(std::min(ctx->num_cus, std::max(1u, (mq.capS + mq.capM + 63) / 64))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.rec_pt, bsum);
+    hipLaunchKernelGGL((k_merge_waves<G>), dim3(std::min(ctx->num_cus, std::max(1u, (mq.capM + mq.capL + 3) / 4))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.rec_pt, w.mq_partial, bsum, w.mq_cnt);
+    hipLaunchKernelGGL((k_merge_final<G>), dim3(std::min(ctx->num_cus, std::max(1u, (mq.capF + 3) / 4))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.mq_partial, bsum, w.mq_cnt);
   }
   // bucket reduction pyramid: one launch per step while a step is wide, then all remaining steps (and the copy of
   // U_{L-1}) in one launch of one block per window (k_pyramid_tail)
   {
     size_t toff = 0;
+    u32 s_begin = 1;
+    if (first2) {   // steps 1 + 2 in one pass over the bucket sums (k_pyramid_first2); the task tables take over at step 3
+      PyrFirst2Args fa; memset(&fa, 0, sizeof fa);
+      fa.nwin = gw; fa.nb = pl.nb; fa.nbw = pl.nbw; fa.nbp = nbp; fa.bucket_off = ar.bucket_off; fa.wstride = nbp;
+      fa.a2_off = ar.apyr_off + nbp / 2;          // offA(2)
+      fa.r02_off = ar.rbuf_off + nbp / 4;         // offR(0, 2)
+      fa.r11_off = ar.rbuf_off + nbp / 2;         // offR(1, 1)
+      fa.scaled = abi ? 1u : 0u;
+      const u32 threads = gw * (nbp / 8);
+      hipLaunchKernelGGL((k_pyramid_first2<G>), dim3((threads + 255) / 256), dim3(256), 0, st, fa, d_bstart, w.arena, w.mq_cnt);
+      toff = pp.steps[0].size() + pp.steps[1].size();
+      s_begin = 3;
+    }
     u32 first_fused = L + 1;
     if (ctx->opt_pyr_fuse == 2)
-      for (u32 s = 1; s <= L; s++) {
+      for (u32 s = s_begin; s <= L; s++) {
         bool fits = true;
         for (u32 q = s; q <= L; q++) if ((size_t)pp.steps[q - 1].size() * pp.step_max_count[q - 1] > 2048) fits = false;
         if (fits && L - s + 1 <= 20) { first_fused = s; break; }
       }
-    for (u32 s = 1; s <= L && s < first_fused; s++) {
+    for (u32 s = s_begin; s <= L && s < first_fused; s++) {
       auto& tasks = pp.steps[s - 1];
       u32 maxc = pp.step_max_count[s - 1];
       size_t threads = (size_t)tasks.size() * maxc * gw;
@@ -658,8 +693,12 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, d_copy, 1u, gw, (u32)ptb, w.arena);
     }
   }
+  {
+    const u32 n16 = (u32)((size_t)gw * (L + 1) * ptb / 16);
+    hipLaunchKernelGGL(k_group_finish, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)(w.arena + (size_t)ar.out_off * ptb), (uint4*)d_out, n16,
+                       w.err, w.meta + META_CLOCK, w.mq_cnt, d_slot);
+  }
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(d_out, w.arena + (size_t)ar.out_off * ptb, (size_t)gw * (L + 1) * ptb, hipMemcpyDeviceToDevice, st));
   if (!w.guards.empty()) {   // debug: drain and verify every guard before the workspace is reused
     std::vector<unsigned char> host(w.guards.size() * WS_GUARD);
     for (size_t i = 0; i < w.guards.size(); i++) HIPCHK(ctx, hipMemcpyAsync(host.data() + i * WS_GUARD, ws_base + w.guards[i], WS_GUARD, hipMemcpyDeviceToHost, st));
@@ -790,7 +829,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   }
   const size_t ng = groups.size();
   const size_t out_slab = align_up((size_t)std::max(nw_pad, 1u) * (L + 1) * ptb, 256);   // one slab's records
-  const size_t ERR_SLOT = 64;   // per (slab, group): err[2] of the digit pass, then k_accum1's clock stamps (4 x u64) at byte 16
+  const size_t ERR_SLOT = 96;   // per (slab, group): err[2] of the digit pass, then k_accum1's clock stamps (4 x u64) at byte 16
   const size_t err_bytes = align_up(std::max<size_t>(nslabs * ng, 1) * ERR_SLOT, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
   int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nslabs + err_bytes + 4096);
@@ -810,7 +849,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   if (one_queue) { s_sort = s_acc; s_tail = s_acc; }   // one queue unless pipelining was asked for: exact event timing
   hipStream_t s_up = ctx->stream_sort;                 // upload queue of the host-pointer path (one_queue is forced there)
   if (hs && !one_queue) return fail(ctx, LEMSM_ERR_BAD_ARG, "option groups > 1 is only available on the device-pointer entries");
-  HIPCHK(ctx, hipStreamSynchronize(s_acc));   // inputs staged / digits produced on the main stream are complete
+  if (!one_queue) HIPCHK(ctx, hipStreamSynchronize(s_acc));   // several queues: inputs staged / digits produced on the main stream are complete (one queue: stream order)
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s_acc));
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
   if (nw_pad != nw || n == 0 || nw == 0)      // record slots no kernel writes (a rank with fewer windows than the widest one) read as identities
@@ -852,14 +891,8 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
       auto src = make_src(s0, sn);
       hipEvent_t* ev = ctx->evpool.data() + 3 * (k * ng + gi);
       rc = run_group<G>(ctx, src, pl, nbp, L, pts, abi, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
-                        s_sort, s_acc, s_tail, ev[0], ev[1], ev[2]);
+                        (u32*)(d_err + (k * ng + gi) * ERR_SLOT), s_sort, s_acc, s_tail, ev[0], ev[1], ev[2]);
       if (rc) return rc;
-      // the group's non-canonical-scalar flag (first 8 bytes of its workspace) survives the workspace reuse
-      HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT, ws_base + gr.off, 8, hipMemcpyDeviceToDevice, s_tail));
-      {
-        GroupWs gw_ = carve(ws_base + gr.off, pl, make_arena(pl.nbins << pl.LB, nbp, gr.g1 - gr.g0, L), make_mq_layout(ctx, pl.nthr1), ptb, ctx->opt_ws_canary != 0);
-        HIPCHK(ctx, hipMemcpyAsync(d_err + (k * ng + gi) * ERR_SLOT + 16, gw_.meta + META_CLOCK, 32, hipMemcpyDeviceToDevice, s_tail));
-      }
     }
     if (!one_queue) {   // three queues share one workspace: drain before the next slab reuses it
       HIPCHK(ctx, hipStreamSynchronize(s_sort));
@@ -894,7 +927,9 @@ int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size
     if (err_bytes) HIPCHK(ctx, hipMemcpyAsync(hp + raw_bytes, wr.d_err, err_bytes, hipMemcpyDeviceToHost, s_tail));
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s_tail));
+  const auto th0 = std::chrono::steady_clock::now();
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+  ctx->host_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
   if (raw_bytes) memcpy(raw.data(), hp, raw_bytes);
   if (err_bytes) memcpy(errw.data(), hp + raw_bytes, err_bytes);
   float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -908,7 +943,10 @@ int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size
       }
     }
   u64 clk_cyc = 0, clk_ticks = 0;
+  for (int q = 0; q < 4; q++) ctx->dbg_merge[q] = 0;
   for (size_t i = 0; i < nerr; i++) {
+    for (int q = 0; q < 4; q++) ctx->dbg_merge[q] += errw[i * (wr.err_slot / 4) + 12 + q];
+    for (int q = 0; q < 8; q++) ctx->dbg_stamps[q] = errw[i * (wr.err_slot / 4) + 16 + q];
     float a = 0; HIPCHK(ctx, hipEventElapsedTime(&a, ctx->evpool[3 * i + 1], ctx->evpool[3 * i + 2]));
     ctx->t_accum_ms += a; ctx->n_accum++;
     u64 ck[4]; memcpy(ck, errw.data() + i * (wr.err_slot / 4) + 4, 32);
@@ -950,7 +988,9 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   std::vector<char> raw;
   rc = run_windows_finish(ctx, wr, wr.d_out, wr.send_bytes(), raw);
   if (rc) return rc;
+  const auto th0 = std::chrono::steady_clock::now();
   sum_slab_records<P64, G>(ctx, raw.data(), wr.out_slab, wr.nslabs, nw, L, host_out);
+  ctx->host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
   return LEMSM_OK;
 }
 
@@ -1002,7 +1042,9 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   int rc = run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, recs);
   if (rc) return rc;
   // this rank's share of the host tail: S_w = total + sum_l 2^l U_l for its own windows
+  const auto th0 = std::chrono::steady_clock::now();
   window_sums_par<P64>(ctx, recs.data(), we - wb, mp.L, out);
+  ctx->host_us[2] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
   return LEMSM_OK;
 }
 
@@ -1030,6 +1072,18 @@ int make_lhs_plan(int curve, u32 base, LhsPlan& lp) {
 
 // digits (position-major, d x n) for the lhs path; leaves err words in ctx workspace tail
 struct LhsDigits { uint8_t* digitsT; u32* err; };
+struct Words12 { u32 w[12]; };
+__global__ void k_set_words12(u32* __restrict__ dst, Words12 v) { if (threadIdx.x < 12) dst[threadIdx.x] = v.w[threadIdx.x]; }
+
+// the range-check words of the digit pass (first offending index, truncation count) travel to the context's small
+// pinned buffer right behind the digit kernel; lhs_err_words waits for that copy (long done when the MSM core returns)
+int lhs_err_words(lemsm_ctx* ctx, size_t n, u32 err[2]) {
+  err[0] = 0xffffffffu; err[1] = 0;
+  if (!n) return LEMSM_OK;
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev[4]));
+  err[0] = ctx->h_small[0]; err[1] = ctx->h_small[1];
+  return LEMSM_OK;
+}
 
 int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const LhsPlan& lp, DevBuf& buf, LhsDigits& out, u32 row_begin, u32 row_end) {
   size_t bytes = align_up((size_t)lp.d * n, 256) + 256 + 64;
@@ -1039,12 +1093,16 @@ int lhs_digits(lemsm_ctx* ctx, int curve, const void* d_scalars, size_t n, const
   out.digitsT = (uint8_t*)base;
   u32* bound_d = (u32*)(base + align_up((size_t)lp.d * n, 256));
   out.err = bound_d + 8;
-  u32 init[12];
-  memcpy(init, bound_of(curve), 32); init[8] = 0xffffffffu; init[9] = 0; init[10] = 0xffffffffu; init[11] = 0;
-  HIPCHK(ctx, hipMemcpyAsync(bound_d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (n) hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)d_scalars, (u32)n,
-                            lp.base, lp.d, bound_d, 1, (uint8_t*)nullptr, out.digitsT, out.err, row_begin, row_end);
+  Words12 init;   // the bound and the initial error words ride in as kernel arguments: no pageable upload, no host wait
+  memcpy(init.w, bound_of(curve), 32); init.w[8] = 0xffffffffu; init.w[9] = 0; init.w[10] = 0xffffffffu; init.w[11] = 0;
+  hipLaunchKernelGGL(k_set_words12, dim3(1), dim3(64), 0, ctx->stream, bound_d, init);
+  if (n) {
+    hipLaunchKernelGGL(k_negbase_digits, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4*)d_scalars, (u32)n,
+                       lp.base, lp.d, bound_d, 1, (uint8_t*)nullptr, out.digitsT, out.err, row_begin, row_end);
+    if (!ctx->h_small) HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_small, 256, hipHostMallocDefault));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_small, out.err, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  }
   HIPCHK(ctx, hipGetLastError());
   return LEMSM_OK;
 }
@@ -1063,11 +1121,8 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, recs);
   if (rc) return rc;
   window_sums_par<P64>(ctx, recs.data(), pe - pb, lp.L, out);
-  u32 err[2] = {0xffffffffu, 0};
-  if (n) {
-    HIPCHK(ctx, hipMemcpyAsync(err, dg.err, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  u32 err[2];
+  { int rce = lhs_err_words(ctx, n, err); if (rce) return rce; }
   ctx->truncated = err[1];
   if (err[0] != 0xffffffffu) {
     if (bad_index) *bad_index = err[0];
@@ -1210,11 +1265,8 @@ int lhs_sharded_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   std::vector<host::pt> all;
   rc = sharded_records<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, lp.d, d_points, ex, all);
   if (rc) return rc;
-  u32 err[2] = {0xffffffffu, 0};
-  if (n) {
-    HIPCHK(ctx, hipMemcpyAsync(err, dg.err, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  u32 err[2];
+  { int rce = lhs_err_words(ctx, n, err); if (rce) return rce; }
   ctx->truncated = err[1];
   if (err[0] != 0xffffffffu) {
     if (bad_index) *bad_index = err[0];
@@ -1420,6 +1472,7 @@ int lemsm_create(int device, lemsm_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return LEMSM_ERR_HIP;
   lemsm_ctx* c = new lemsm_ctx();
   c->device = device;
+  c->num_cus = prop.multiProcessorCount > 0 ? (u32)prop.multiProcessorCount : 256u;
   {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
@@ -1427,7 +1480,7 @@ int lemsm_create(int device, lemsm_ctx** out) {
         hipStreamCreateWithPriority(&c->stream_sort, hipStreamNonBlocking, hi) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream_tail, hipStreamNonBlocking, hi) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
   }
-  for (int i = 0; i < 4; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
+  for (int i = 0; i < 5; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return LEMSM_ERR_HIP; }
   *out = c;
   return LEMSM_OK;
 }
@@ -1442,9 +1495,10 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   if (ctx->comm) { (void)Rccl::get().CommDestroy(ctx->comm); ctx->comm = nullptr; }
   ctx->pool.reset();
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->h_small) (void)hipHostFree(ctx->h_small);
   for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather, &ctx->dw_tab, &ctx->dw_arena, &ctx->dw_tmp}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
-  for (int i = 0; i < 4; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1459,6 +1513,8 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "tile")) { if (value < 0 || (value && value < 256)) return LEMSM_ERR_BAD_ARG; ctx->opt_tile = value; }
   else if (!strcmp(name, "groups")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_groups = value; }
   else if (!strcmp(name, "merge_slice")) { if (value != 0 && (value < 33 || value > 65536)) return LEMSM_ERR_BAD_ARG; ctx->opt_merge_slice = value; }
+  else if (!strcmp(name, "dbg_repeat")) { ctx->opt_dbg_repeat = value; }
+  else if (!strcmp(name, "pyr_first2")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_first2 = value; }
   else if (!strcmp(name, "merge_wave_th")) { if (value < 0 || value > (1 << 24)) return LEMSM_ERR_BAD_ARG; ctx->opt_merge_wave_th = value; }
   else if (!strcmp(name, "abi_points")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_abi_points = value; }
   else if (!strcmp(name, "stage2x")) { if (value < 0 || value > 4 || value == 3) return LEMSM_ERR_BAD_ARG; ctx->opt_stage2x = value; }
@@ -1486,6 +1542,14 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx) { return ctx ? ctx->trun
 int lemsm_last_timing(const lemsm_ctx* ctx, double out[3]) {
   if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
   out[0] = ctx->t_total_ms; out[1] = ctx->t_accum_ms; out[2] = ctx->n_accum;
+  return LEMSM_OK;
+}
+
+int lemsm_debug_last_merge_counts(const lemsm_ctx* ctx, uint64_t out[4]) {
+  if (!ctx || !out) return LEMSM_ERR_BAD_ARG;
+  for (int q = 0; q < 4; q++) out[q] = ctx->dbg_merge[q];
+  if (getenv("LEMSM_DEBUG_STAMPS")) fprintf(stderr, "[lemsm] merge stamps (cycles): queues wave0: setup %u sum %u store %u n %u | final wave0: setup %u sum %u store %u n %u\n",
+                                            ctx->dbg_stamps[0], ctx->dbg_stamps[1], ctx->dbg_stamps[2], ctx->dbg_stamps[3] & 0x7fffffffu, ctx->dbg_stamps[4], ctx->dbg_stamps[5], ctx->dbg_stamps[6], ctx->dbg_stamps[7]);
   return LEMSM_OK;
 }
 
@@ -1538,8 +1602,11 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   std::vector<host::pt> sums;
   rc = msm_partial_dispatch(ctx, curve, d_scalars, d_points, n, 0, mp.W, sums);
   if (rc) return rc;
+  const auto th0 = std::chrono::steady_clock::now();
   if (curve == LEMSM_BN254_G1) msm_combine_t<host::FqParams64>(mp, sums.data(), out);
   else msm_combine_t<host::FrParams64>(mp, sums.data(), out);
+  ctx->host_us[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
+  if (getenv("LEMSM_DEBUG_STAMPS")) fprintf(stderr, "[lemsm] host tail (us): device wait %.1f, records %.1f, window sums %.1f, Horner %.1f\n", ctx->host_us[0], ctx->host_us[1], ctx->host_us[2], ctx->host_us[3]);
   return LEMSM_OK;
 }
 

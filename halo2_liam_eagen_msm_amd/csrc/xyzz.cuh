@@ -129,12 +129,30 @@ struct XYZZ {
 
   static __device__ __forceinline__ void neg(pt& p) { F::neg(p.y, p.y); }
 
-  // every lane receives lane `src`'s point (wave64; src may differ per lane)
-  static __device__ __forceinline__ void shfl(pt& r, const pt& p, int src) {
+  // One step of the wave-level inclusive scan over points (GFX9 DPP, the sequence the compiler uses for wave
+  // reductions): steps 0..3 fetch the lane 1, 2, 4, 8 places below inside the 16-lane row, step 4 gives rows 1 and 3
+  // the last lane of the row below (row_bcast:15), step 5 gives rows 2 and 3 lane 31 (row_bcast:31); a lane without a
+  // source receives the identity (all-zero limbs).  DPP moves are plain VALU instructions: a 36-limb fetch costs a
+  // few hundred cycles where 36 ds_bpermute cost ~10 000 (tools/ubench/add_latency.hip), and in a scan every lane keeps
+  // adding real data, which matters: an addition only a few lanes take runs 1.7-3x slower than a full-wave one.
+  template <int CTRL, int ROW_MASK>
+  static __device__ __forceinline__ void dpp_move(pt& r, const pt& p) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      r.x.v[i] = __shfl(p.x.v[i], src); r.y.v[i] = __shfl(p.y.v[i], src);
-      r.zz.v[i] = __shfl(p.zz.v[i], src); r.zzz.v[i] = __shfl(p.zzz.v[i], src);
+      r.x.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)p.x.v[i], CTRL, ROW_MASK, 0xf, false);
+      r.y.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)p.y.v[i], CTRL, ROW_MASK, 0xf, false);
+      r.zz.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)p.zz.v[i], CTRL, ROW_MASK, 0xf, false);
+      r.zzz.v[i] = (u32)__builtin_amdgcn_update_dpp(0, (int)p.zzz.v[i], CTRL, ROW_MASK, 0xf, false);
+    }
+  }
+  static __device__ __forceinline__ void scan_fetch(pt& r, const pt& p, int step) {
+    switch (step) {
+      case 0: dpp_move<0x111, 0xf>(r, p); break;   // row_shr:1
+      case 1: dpp_move<0x112, 0xf>(r, p); break;   // row_shr:2
+      case 2: dpp_move<0x114, 0xf>(r, p); break;   // row_shr:4
+      case 3: dpp_move<0x118, 0xf>(r, p); break;   // row_shr:8
+      case 4: dpp_move<0x142, 0xa>(r, p); break;   // row_bcast:15 into rows 1, 3
+      default: dpp_move<0x143, 0xc>(r, p); break;  // row_bcast:31 into rows 2, 3
     }
   }
 
@@ -143,6 +161,15 @@ struct XYZZ {
   static __device__ __forceinline__ void load(pt& p, const void* mem) {
     const char* m = reinterpret_cast<const char*>(mem);
     F::load(p.x, m); F::load(p.y, m + 32); F::load(p.zz, m + 64); F::load(p.zzz, m + 96);
+  }
+  static constexpr int RAW_WORDS = 8;
+  static __device__ __forceinline__ void load_raw(uint4 (&r)[RAW_WORDS], const void* mem) {
+    const uint4* q = reinterpret_cast<const uint4*>(mem);
+#pragma unroll
+    for (int i = 0; i < RAW_WORDS; i++) r[i] = q[i];
+  }
+  static __device__ __forceinline__ void from_raw(pt& p, const uint4 (&r)[RAW_WORDS]) {
+    F::from_words(p.x, r[0], r[1]); F::from_words(p.y, r[2], r[3]); F::from_words(p.zz, r[4], r[5]); F::from_words(p.zzz, r[6], r[7]);
   }
   static __device__ __forceinline__ void store(void* mem, const pt& p) {
     char* m = reinterpret_cast<char*>(mem);

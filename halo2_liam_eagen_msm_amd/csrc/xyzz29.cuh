@@ -202,12 +202,30 @@ struct XYZZ29 {
     F::mul(t, acc.zzz, q.zzz); F::mul(acc.zzz, t, PPP);
   }
 
-  // every lane receives lane `src`'s point (wave64; src may differ per lane)
-  static __device__ __forceinline__ void shfl(pt& r, const pt& p, int src) {
+  // One step of the wave-level inclusive scan over points (GFX9 DPP, the sequence the compiler uses for wave
+  // reductions): steps 0..3 fetch the lane 1, 2, 4, 8 places below inside the 16-lane row, step 4 gives rows 1 and 3
+  // the last lane of the row below (row_bcast:15), step 5 gives rows 2 and 3 lane 31 (row_bcast:31); a lane without a
+  // source receives the identity (all-zero limbs).  DPP moves are plain VALU instructions: a 36-limb fetch costs a
+  // few hundred cycles where 36 ds_bpermute cost ~10 000 (tools/ubench/add_latency.hip), and in a scan every lane keeps
+  // adding real data, which matters: an addition only a few lanes take runs 1.7-3x slower than a full-wave one.
+  template <int CTRL, int ROW_MASK>
+  static __device__ __forceinline__ void dpp_move(pt& r, const pt& p) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-      r.x.l[i] = __shfl(p.x.l[i], src); r.y.l[i] = __shfl(p.y.l[i], src);
-      r.zz.l[i] = __shfl(p.zz.l[i], src); r.zzz.l[i] = __shfl(p.zzz.l[i], src);
+      r.x.l[i] = (i32)__builtin_amdgcn_update_dpp(0, (int)p.x.l[i], CTRL, ROW_MASK, 0xf, false);
+      r.y.l[i] = (i32)__builtin_amdgcn_update_dpp(0, (int)p.y.l[i], CTRL, ROW_MASK, 0xf, false);
+      r.zz.l[i] = (i32)__builtin_amdgcn_update_dpp(0, (int)p.zz.l[i], CTRL, ROW_MASK, 0xf, false);
+      r.zzz.l[i] = (i32)__builtin_amdgcn_update_dpp(0, (int)p.zzz.l[i], CTRL, ROW_MASK, 0xf, false);
+    }
+  }
+  static __device__ __forceinline__ void scan_fetch(pt& r, const pt& p, int step) {
+    switch (step) {
+      case 0: dpp_move<0x111, 0xf>(r, p); break;   // row_shr:1
+      case 1: dpp_move<0x112, 0xf>(r, p); break;   // row_shr:2
+      case 2: dpp_move<0x114, 0xf>(r, p); break;   // row_shr:4
+      case 3: dpp_move<0x118, 0xf>(r, p); break;   // row_shr:8
+      case 4: dpp_move<0x142, 0xa>(r, p); break;   // row_bcast:15 into rows 1, 3
+      default: dpp_move<0x143, 0xc>(r, p); break;  // row_bcast:31 into rows 2, 3
     }
   }
 
@@ -222,6 +240,20 @@ struct XYZZ29 {
     u32 w[40];
 #pragma unroll
     for (int i = 0; i < 10; i++) { uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { p.x.l[i] = (i32)w[i]; p.y.l[i] = (i32)w[9 + i]; p.zz.l[i] = (i32)w[18 + i]; p.zzz.l[i] = (i32)w[27 + i]; }
+  }
+  // the same in two halves: request the 16-byte words now, turn them into limbs later (prefetch across an addition)
+  static constexpr int RAW_WORDS = 9;
+  static __device__ __forceinline__ void load_raw(uint4 (&r)[RAW_WORDS], const void* mem) {
+    const uint4* q = reinterpret_cast<const uint4*>(mem);
+#pragma unroll
+    for (int i = 0; i < RAW_WORDS; i++) r[i] = q[i];
+  }
+  static __device__ __forceinline__ void from_raw(pt& p, const uint4 (&r)[RAW_WORDS]) {
+    u32 w[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { w[4 * i] = r[i].x; w[4 * i + 1] = r[i].y; w[4 * i + 2] = r[i].z; w[4 * i + 3] = r[i].w; }
 #pragma unroll
     for (int i = 0; i < 9; i++) { p.x.l[i] = (i32)w[i]; p.y.l[i] = (i32)w[9 + i]; p.zz.l[i] = (i32)w[18 + i]; p.zzz.l[i] = (i32)w[27 + i]; }
   }

@@ -101,7 +101,8 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    "abi_points" (lazy arithmetic: 1 = convert the points to the kernels' domain in a pass of their
    own, 2 = let the accumulation consume them as passed in, 0 = choose by segment length and window
    count), "pyr_fuse" (0 = one launch per step of the bucket-reduction pyramid, 2 = the narrow last steps in one launch of one
-   block per window: A/B knob, measured slower), "host_threads" (host tail: 0 = up to 8 threads, 1 = serial), "ntt_tiled" (divisor witness: 0 = LDS-tiled transforms, up to 10 stages per launch; 2 = one launch per
+   block per window: A/B knob, measured slower), "host_threads" (host tail: 0 = up to 8 threads, 1 = serial), "pyr_first2" (1 = the first two pyramid steps in one pass over the bucket sums where the window has
+   >= 32 buckets -- half the HBM traffic of the two launches, measured no faster: A/B knob; 0 = one launch per step), "ntt_tiled" (divisor witness: 0 = LDS-tiled transforms, up to 10 stages per launch; 2 = one launch per
    stage: A/B knob), "dw_kb" (divisor witness: slots per thread of the batched-inversion kernels, 8..64; 0 = auto),
    "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
    input from the coefficient arrays and the last inverse pass scatters into them; 2 = separate load / store kernels:
@@ -120,6 +121,10 @@ int lemsm_last_timing(const lemsm_ctx* ctx, double out[3]);
 /* Shader clock (MHz) the accumulate kernel of the last MSM call sustained, from in-kernel stamps
    (s_memtime / s_memrealtime around one mid-grid wave's whole chunk); 0 if no launch stamped. */
 int lemsm_last_accum_clock_mhz(const lemsm_ctx* ctx, double* out);
+/* Test / profiling aid: how the edge-record merge of the last MSM call classified the buckets that straddle
+   accumulate chunks, summed over window groups and slabs: [0] 3..8 pieces (serial), [1] 9..32 pieces,
+   [2] slices of buckets of more than 32 pieces, [3] buckets of several slices.  Two-piece buckets are not counted. */
+int lemsm_debug_last_merge_counts(const lemsm_ctx* ctx, uint64_t out[4]);
 
 /* ---- best_multiexp ------------------------------------------------------------------- */
 /* sum_i scalars[i] * points[i]; host buffers. */

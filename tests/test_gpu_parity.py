@@ -225,6 +225,61 @@ def test_msm_extreme_skew_at_scale(fctx, logn):
     assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, same.ptr, n)) == canon(curve, cref.scalar_mul(curve.cid, k2, q))
 
 
+@pytest.mark.parametrize("chunk,slice_,wave_th,digits", [(8, 0, 0, 40), (8, 0, 1, 40), (8, 33, 0, 2), (8, 33, 0, 3), (1, 64, 0, 300), (3, 0, 0, 1000), (17, 100, 3, 20)])
+def test_msm_edge_record_merge_every_class(fctx, chunk, slice_, wave_th, digits):
+    """the merge of the pieces a bucket leaves in the accumulate chunks it straddles (kernels_ec.cuh): scalars drawn from a
+    small alphabet give buckets of n / digits entries, so that with short chunks every size class is met -- two pieces,
+    3..8 (serial), 9..32 (one wave each, or serial when option merge_wave_th says so), slices of long buckets and the
+    final pass over a multi-slice bucket's partial sums; the queue counters say which of them ran"""
+    ctx = fctx
+    curve = pyref.BN254_G1
+    n = 6000
+    rng = np.random.default_rng(chunk * 1000 + digits)
+    alphabet = cref.gen_scalars(curve.cid, 900 + digits, digits)
+    sc = alphabet[rng.integers(0, digits, n)]
+    pts = cref.gen_points(curve.cid, 901, 128)
+    pts = np.tile(pts, (n // 128 + 1, 1))[:n]
+    for k, v in (("window_bits", 13), ("chunk", chunk), ("merge_slice", slice_), ("merge_wave_th", wave_th)):
+        ctx.set_option(k, v)
+    try:
+        out = ctx.msm(curve.cid, sc, pts)
+        counts = ctx.last_merge_counts()
+    finally:
+        for k in ("window_bits", "chunk", "merge_slice", "merge_wave_th"):
+            ctx.set_option(k, 0)
+    assert canon(curve, out) == canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    pieces = n / digits / chunk                       # of a typical bucket
+    if pieces > 40:
+        assert counts[2] > 0, counts                  # long buckets were sliced
+        if slice_ and pieces > 2 * slice_:
+            assert counts[3] > 0, counts              # and the multi-slice final pass ran
+    elif 10 < pieces < 30:
+        assert counts[1] > 0, counts
+    elif 3.5 < pieces < 7:
+        assert counts[0] > 0, counts
+
+
+def test_lhs_edge_record_merge_long_buckets(fctx):
+    """negabase digits: B - 1 buckets per position, so every bucket is long; small slices force several per bucket"""
+    ctx = fctx
+    curve = pyref.GRUMPKIN
+    n = 5000
+    pts = cref.gen_points(curve.cid, 910, n)
+    sc = cref.gen_scalars(curve.cid, 911, n, half=True)
+    jac = cref.aff_to_jac(curve.cid, pts)
+    ctx.set_option("merge_slice", 40); ctx.set_option("chunk", 4)
+    try:
+        carry, carries = ctx.lhs_msm(curve.cid, sc, jac, 5)
+        counts = ctx.last_merge_counts()
+    finally:
+        ctx.set_option("merge_slice", 0); ctx.set_option("chunk", 0)
+    ecarry, ecarries = cref.lhs_msm(curve.cid, sc, jac, 5)
+    assert canon(curve, carry) == canon(curve, ecarry)
+    for i in range(carries.shape[0]):
+        assert canon(curve, carries[i]) == canon(curve, ecarries[i])
+    assert counts[2] > 0 and counts[3] > 0, counts
+
+
 def test_msm_all_zero_scalars_and_all_identity_points(fctx):
     ctx = fctx
     curve = pyref.GRUMPKIN
