@@ -549,7 +549,8 @@ template <class G, class Prov>
 int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u32 L, const void* d_points,
               bool abi /* d_points are in the C ABI's domain: k_accum1<.., true>, scaled outputs */,
               char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, u32* d_slot /* device, this (slab, group)'s 64-byte status slot */, hipStream_t s_sort, hipStream_t s_acc,
-              hipStream_t s_tail, hipEvent_t ev_sorted, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
+              hipStream_t s_tail, hipEvent_t ev_sorted, hipEvent_t ev_acc0, hipEvent_t ev_acc1,
+              hipEvent_t ev_points /* null, or: the converted points become ready on another queue */ = nullptr) {
   // Three queues: the sort passes of this group may run while the previous group accumulates
   // (s_sort), the accumulate kernels of all groups run back to back (s_acc), and this group's
   // edge-record levels + pyramid overlap the next group's accumulation (s_tail).
@@ -619,6 +620,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   HIPCHK(ctx, hipEventRecord(ev_sorted, s_sort));
   st = s_acc;
   HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_sorted, 0));
+  if (ev_points) HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_points, 0));
   HIPCHK(ctx, hipEventRecord(ev_acc0, s_acc));
   {
     dim3 grid((pl.nthr1 + 255) / 256), blk(256);
@@ -870,6 +872,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
     // wave opens a segment).  With S = average segment length the second costs P = 1-(1-1/S)^64 of
     // 110/2058 of the accumulation (68 ps per point and window): cheaper when P * windows < 7.
     bool abi = false;
+    hipEvent_t ev_points = nullptr;
     ctx->plan_ring = false;
     if constexpr (G::CONVERTED_DOMAIN) {
       GroupPlan pl0 = make_group_plan(ctx, sn, c, nb, W, groups[0].g0, groups[0].g1, d);
@@ -880,7 +883,18 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
       if (ctx->opt_abi_points == 2) abi = (ctx->opt_accum_waves == 0 || ctx->opt_accum_waves == 3);
       ctx->plan_ring = abi && ctx->opt_entry_ring != 1;
       if (!abi) {
-        hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, s_acc, (const uint4*)pts, (uint4*)d_conv, sn);
+        if (one_queue && !hs) {
+          // the conversion (HBM-bound, 2 x 64 B per point) runs on the second queue beside this slab's digit and sort passes
+          // (latency- and atomic-bound); it may start once everything enqueued so far -- the previous slab's accumulation,
+          // which still reads d_conv -- is done, and the accumulate kernel waits for it
+          HIPCHK(ctx, hipEventRecord(ctx->ev[2], s_acc));
+          HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_sort, ctx->ev[2], 0));
+          hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, ctx->stream_sort, (const uint4*)pts, (uint4*)d_conv, sn);
+          HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream_sort));
+          ev_points = ctx->ev[3];
+        } else {
+          hipLaunchKernelGGL((k_convert_points<typename G::F_>), dim3((2 * sn + 255) / 256), dim3(256), 0, s_acc, (const uint4*)pts, (uint4*)d_conv, sn);
+        }
         pts = d_conv;
       }
     }
@@ -891,7 +905,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
       auto src = make_src(s0, sn);
       hipEvent_t* ev = ctx->evpool.data() + 3 * (k * ng + gi);
       rc = run_group<G>(ctx, src, pl, nbp, L, pts, abi, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
-                        (u32*)(d_err + (k * ng + gi) * ERR_SLOT), s_sort, s_acc, s_tail, ev[0], ev[1], ev[2]);
+                        (u32*)(d_err + (k * ng + gi) * ERR_SLOT), s_sort, s_acc, s_tail, ev[0], ev[1], ev[2], gi == 0 ? ev_points : nullptr);
       if (rc) return rc;
     }
     if (!one_queue) {   // three queues share one workspace: drain before the next slab reuses it
@@ -956,20 +970,31 @@ int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size
   return LEMSM_OK;
 }
 
+// S_w = total + sum_l 2^l U_l  for one window record [total, U_0..U_{L-1}]
+template <class P64>
+host::pt window_sum(const host::pt* rec, u32 L) {
+  typedef host::HG<P64> G;
+  host::pt acc = G::identity();
+  for (int l = (int)L - 1; l >= 0; l--) { acc = G::dbl(acc); acc = G::add(acc, rec[1 + l]); }
+  return G::add(acc, rec[0]);
+}
+
 // host: records of nw windows = sum over the slabs of one rank's record area (raw: nslabs blocks of out_slab bytes)
 template <class P64, class G>
-void sum_slab_records(lemsm_ctx* ctx, const char* raw, size_t out_slab, size_t nslabs, u32 nw, u32 L, std::vector<host::pt>& host_out) {
+void sum_slab_records(lemsm_ctx* ctx, const char* raw, size_t out_slab, size_t nslabs, u32 nw, u32 L, std::vector<host::pt>& host_out,
+                      bool fold = false /* leave the nw window sums S_w = total + sum_l 2^l U_l instead of the records */) {
   typedef host::HG<P64> HGp;
   const size_t ptb = G::PT_BYTES;
-  host_out.assign((size_t)nw * (L + 1), HGp::identity());
-  host_parallel(ctx, (int)nw, [&](int w) {        // one job per window: its L + 1 records of every slab
-    std::vector<host::pt> tmp(L + 1);
-    host::pt* dst = host_out.data() + (size_t)w * (L + 1);
+  host_out.assign(fold ? (size_t)nw : (size_t)nw * (L + 1), HGp::identity());
+  host_parallel(ctx, (int)nw, [&](int w) {        // one job per window: its L + 1 records of every slab (and their Horner fold)
+    std::vector<host::pt> tmp(L + 1), acc(L + 1);
+    host::pt* dst = fold ? acc.data() : host_out.data() + (size_t)w * (L + 1);
     for (size_t k = 0; k < nslabs; k++) {
       from_device_records<P64, G>(raw + k * out_slab + (size_t)w * (L + 1) * ptb, L + 1, tmp.data());
       if (k == 0) memcpy(dst, tmp.data(), (L + 1) * sizeof(host::pt));
       else for (u32 i = 0; i <= L; i++) dst[i] = HGp::add(dst[i], tmp[i]);
     }
+    if (fold) host_out[w] = window_sum<P64>(dst, L);
   });
 }
 
@@ -977,10 +1002,10 @@ void sum_slab_records(lemsm_ctx* ctx, const char* raw, size_t out_slab, size_t n
 // (we-wb) x (L+1) XYZZ points, summed over slabs.
 template <class P64, class G, class MakeSrc>
 int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 wb, u32 we, u32 d,
-                const void* d_points, std::vector<host::pt>& host_out) {
+                const void* d_points, std::vector<host::pt>& host_out, bool fold = false /* window sums instead of records */) {
   typedef host::HG<P64> HGp;
   u32 nw = we - wb;
-  host_out.assign((size_t)nw * (L + 1), HGp::identity());
+  host_out.assign(fold ? (size_t)nw : (size_t)nw * (L + 1), HGp::identity());
   if (n == 0 || nw == 0) return LEMSM_OK;
   WinRun wr;
   int rc = run_windows_enqueue<P64, G>(ctx, make_src, n, c, nb, nbp, L, W, wb, we, d, d_points, nw, wr);
@@ -989,18 +1014,9 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   rc = run_windows_finish(ctx, wr, wr.d_out, wr.send_bytes(), raw);
   if (rc) return rc;
   const auto th0 = std::chrono::steady_clock::now();
-  sum_slab_records<P64, G>(ctx, raw.data(), wr.out_slab, wr.nslabs, nw, L, host_out);
+  sum_slab_records<P64, G>(ctx, raw.data(), wr.out_slab, wr.nslabs, nw, L, host_out, fold);
   ctx->host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
   return LEMSM_OK;
-}
-
-// S_w = total + sum_l 2^l U_l  for one window record [total, U_0..U_{L-1}]
-template <class P64>
-host::pt window_sum(const host::pt* rec, u32 L) {
-  typedef host::HG<P64> G;
-  host::pt acc = G::identity();
-  for (int l = (int)L - 1; l >= 0; l--) { acc = G::dbl(acc); acc = G::add(acc, rec[1 + l]); }
-  return G::add(acc, rec[0]);
 }
 
 // the window sums of one call, one pool job per window (L doublings + L + 1 additions each)
@@ -1038,14 +1054,10 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
     PipProvider s; s.scalars = (const uint4*)((const char*)d_scalars + s0 * 32);
     memcpy(s.kadd.k, mp.kadd, 32); memcpy(s.kadd.order, order_of(curve), 32); return s;
   };
-  std::vector<host::pt> recs;
-  int rc = run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, recs);
-  if (rc) return rc;
-  // this rank's share of the host tail: S_w = total + sum_l 2^l U_l for its own windows
-  const auto th0 = std::chrono::steady_clock::now();
-  window_sums_par<P64>(ctx, recs.data(), we - wb, mp.L, out);
-  ctx->host_us[2] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
-  return LEMSM_OK;
+  // conversion of the raw records and this rank's share of the host tail (S_w = total + sum_l 2^l U_l for its own
+  // windows) in one pool job per window
+  int rc = run_windows<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, wb, we, 0, d_points, out, true);
+  return rc;
 }
 
 int check_curve(lemsm_ctx* ctx, int curve) {
@@ -1117,10 +1129,8 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   if (rc) return rc;
   // the digit matrix is position-major over the whole n; slabs index it with an offset
   auto make_src = [&](size_t s0, u32) { NegProvider s; s.digitsT = dg.digitsT + s0; return s; };
-  std::vector<host::pt> recs;
-  rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, recs);
+  rc = run_windows<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, pb, pe, lp.d, d_points, out, true);
   if (rc) return rc;
-  window_sums_par<P64>(ctx, recs.data(), pe - pb, lp.L, out);
   u32 err[2];
   { int rce = lhs_err_words(ctx, n, err); if (rce) return rce; }
   ctx->truncated = err[1];
@@ -1606,7 +1616,7 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   if (curve == LEMSM_BN254_G1) msm_combine_t<host::FqParams64>(mp, sums.data(), out);
   else msm_combine_t<host::FrParams64>(mp, sums.data(), out);
   ctx->host_us[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
-  if (getenv("LEMSM_DEBUG_STAMPS")) fprintf(stderr, "[lemsm] host tail (us): device wait %.1f, records %.1f, window sums %.1f, Horner %.1f\n", ctx->host_us[0], ctx->host_us[1], ctx->host_us[2], ctx->host_us[3]);
+  if (getenv("LEMSM_DEBUG_STAMPS")) fprintf(stderr, "[lemsm] host tail (us): device wait %.1f, records + window sums %.1f, (unused) %.1f, Horner %.1f\n", ctx->host_us[0], ctx->host_us[1], ctx->host_us[2], ctx->host_us[3]);
   return LEMSM_OK;
 }
 
