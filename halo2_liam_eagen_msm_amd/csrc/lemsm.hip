@@ -609,7 +609,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     if (pl.bin_cap && pl.bin_cap <= BIN_CAP_SMALL) hipLaunchKernelGGL((k_binsort<BIN_CAP_SMALL>), dim3(pl.nbins), dim3(1024), 0, st, pl, w.entries, w.bin_start, w.sorted, w.bucket_start);
     else if (pl.bin_cap) hipLaunchKernelGGL((k_binsort<BIN_CAP>), dim3(pl.nbins), dim3(1024), 0, st, pl, w.entries, w.bin_start, w.sorted, w.bucket_start);
     hipLaunchKernelGGL(k_tilemap, dim3((pl.max_tiles + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.tile_prefix, w.meta, w.tile_info);
-    const u32 g2 = pl.bin_cap ? std::min(pl.max_tiles, 2048u) : pl.max_tiles;   // with k_binsort the tiled kernels see the oversize bins only: a small grid walks the (usually empty) tile table
+    const u32 g2 = pl.bin_cap ? std::min(pl.max_tiles, 768u) : pl.max_tiles;   // with k_binsort the tiled kernels see the oversize bins only: a small grid walks the (usually empty) tile table
     hipLaunchKernelGGL(k_count2, dim3(g2), dim3(256), 0, st, pl, w.entries, w.tile_info, w.bucket_count);
     hipLaunchKernelGGL(k_bucketscan, dim3(((pl.nbins << pl.LB) + 255) / 256), dim3(256), 0, st, pl, w.bin_start, w.bucket_count, w.bucket_start);
     hipLaunchKernelGGL(k_scatter2, dim3(g2), dim3(256), 0, st, pl, w.entries, w.tile_info,
@@ -669,12 +669,19 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       s_begin = 3;
     }
     u32 first_fused = L + 1;
-    if (ctx->opt_pyr_fuse == 2)
+    // the last steps in ONE launch of one block per window (k_pyramid_tail) from where a window's whole step is at most
+    // `lim` items: 256 by default -- one wave per SIMD of the block's CU, so a fused step costs one addition (~6.5 us)
+    // where a launch of its own costs ~10; with more items per step the block's waves share SIMDs and a fused step
+    // gets slower than a launch spread over the chip (option pyr_fuse = 2: 2048, measured slower; 1: never fuse)
+    if (ctx->opt_pyr_fuse != 1) {
+      const size_t lim = ctx->opt_pyr_fuse == 2 ? 2048 : 256;
       for (u32 s = s_begin; s <= L; s++) {
         bool fits = true;
-        for (u32 q = s; q <= L; q++) if ((size_t)pp.steps[q - 1].size() * pp.step_max_count[q - 1] > 2048) fits = false;
+        for (u32 q = s; q <= L; q++) if ((size_t)pp.steps[q - 1].size() * pp.step_max_count[q - 1] > lim) fits = false;
         if (fits && L - s + 1 <= 20) { first_fused = s; break; }
       }
+      if (first_fused == L) first_fused = L + 1;   // a single step gains nothing
+    }
     for (u32 s = s_begin; s <= L && s < first_fused; s++) {
       auto& tasks = pp.steps[s - 1];
       u32 maxc = pp.step_max_count[s - 1];

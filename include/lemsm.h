@@ -100,8 +100,8 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    0 = auto = 2049; 1 = always serial),
    "abi_points" (lazy arithmetic: 1 = convert the points to the kernels' domain in a pass of their
    own, 2 = let the accumulation consume them as passed in, 0 = choose by segment length and window
-   count), "pyr_fuse" (0 = one launch per step of the bucket-reduction pyramid, 2 = the narrow last steps in one launch of one
-   block per window: A/B knob, measured slower), "host_threads" (host tail: 0 = up to 8 threads, 1 = serial), "pyr_first2" (1 = the first two pyramid steps in one pass over the bucket sums where the window has
+   count), "pyr_fuse" (bucket-reduction pyramid: 0 = one launch per step while a window's step has more than 256 items, the
+   rest in one launch of one block per window; 1 = one launch per step throughout; 2 = fuse from 2048 items: A/B knob), "host_threads" (host tail: 0 = up to 8 threads, 1 = serial), "pyr_first2" (1 = the first two pyramid steps in one pass over the bucket sums where the window has
    >= 32 buckets -- half the HBM traffic of the two launches, measured no faster: A/B knob; 0 = one launch per step), "ntt_tiled" (divisor witness: 0 = LDS-tiled transforms, up to 10 stages per launch; 2 = one launch per
    stage: A/B knob), "dw_kb" (divisor witness: slots per thread of the batched-inversion kernels, 8..64; 0 = auto),
    "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its

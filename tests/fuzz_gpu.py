@@ -154,7 +154,7 @@ def main(secs=None, seed=None):
                 "slab_bits": int(rng.choice([0, 0, 12, 14])), "merge_slice": int(rng.choice([0, 0, 33, 64, 100])), "merge_wave_th": int(rng.choice([0, 0, 1, 3])),
                 "accum_waves": int(rng.choice([0, 0, 2, 4])), "host_slab_bits": int(rng.choice([0, 12, 13, 16])),
                 "groups": 0, "entry_ring": int(rng.integers(0, 2)), "xcd_windows": int(rng.integers(0, 2)),
-                "ws_canary": int(rng.random() < 0.3), "pyr_fuse": 2 * int(rng.random() < 0.3), "pyr_first2": int(rng.random() < 0.3),
+                "ws_canary": int(rng.random() < 0.3), "pyr_fuse": int(rng.choice([0, 0, 1, 2])), "pyr_first2": int(rng.random() < 0.3),
                 "binsort": int(rng.choice([0, 0, 2, 3, 40, 700])), "dw_wrap": int(rng.choice([0, 0, 2])), "dw_fuse": int(rng.choice([0, 0, 2]))}     # 2: tiled pass 2 only; > 2: a bin capacity that splits the bins between both paths
         host_entry = rng.random() < 0.5
         if not host_entry:
