@@ -209,7 +209,7 @@ def main():
         launches_per_step = launches / args.steps
         achieved = BYTES_PER_PAIR * n / world / launches_per_step / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.workload, curve, logn, world),
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None if args.option else pmc_traffic(args.workload, curve, logn, world),   # (an --option run is not the plan the PMC passes measured)
                     "traffic_source": "committed rocprofv3 PMC passes of this command (profiles/traffic_accum1.json), not measured in this run",
                     "kernel": "k_accum1", "kernel_ms": round(accum_ms, 4), "launches_per_step": launches_per_step, "pipeline_device_ms": round(tot_ms / args.steps, 4),
                     "note": "integer-ALU-bound path: 96 algorithmic B/pair vs 8 TB/s HBM; see DESIGN.md for the VALU roofline"}
@@ -404,29 +404,34 @@ def _download_elems(ctx, buf, off_elems, count):
 
 
 def cpu_baseline_lhs_witness(ctx, cid, scalars, d_points, args):
-    """Oracle leg: compute_lhs_witness of a bounded sample through the big-int restatement of the reference (oracle/divisor.py:
-    serial group arithmetic, Kronecker-substitution polynomial products), one thread, timed; the GPU result on the same
-    sample compared function by function, coefficient by coefficient (after normalising the coefficient of highest pole
-    order, a RegularFunction being defined up to a scalar)."""
+    """Oracle leg: compute_lhs_witness of a bounded sample through the compiled, threaded restatement of the reference
+    (oracle/c/witness_oracle.inc: schoolbook products below 32 coefficients, radix-2 FFT with the pinned omega above, the d
+    merge trees spread over the host threads this process may use), timed; the GPU result on the same sample compared
+    function by function, coefficient by coefficient (after normalising the coefficient of highest pole order, a
+    RegularFunction being defined up to a scalar).  tests/test_oracle_golden.py pins that restatement to oracle/divisor.py."""
     import json as _json
-    from oracle import pyref, divisor as dv
+    from oracle import pyref, divisor as dv, cref
     g = pyref.GRUMPKIN; p = g.fp
-    slog = args.cpu_sample_log if args.cpu_sample_log is not None else 12      # ~10-20 s of the Python restatement
+    slog = args.cpu_sample_log if args.cpu_sample_log is not None else 14      # ~10 s on 16 threads
     slog = min(slog, int(math.log2(scalars.shape[0])))
     m = 1 << slog
-    head = int.from_bytes(bytes.fromhex(_json.load(open(os.path.join(ROOT, "tests", "golden", "fr_mont_chains.json")))["omega_pow"]["head"]), "little")
-    O = dv.DivisorOracle(g, dv.FrFft(p, head * pow(1 << 256, -1, p) % p))
+    head_bytes = bytes.fromhex(_json.load(open(os.path.join(ROOT, "tests", "golden", "fr_mont_chains.json")))["omega_pow"]["head"])
+    omega_raw = np.frombuffer(head_bytes, np.uint64).copy()
+    O = dv.DivisorOracle(g, None)                   # (normalise / to_affine only)
     rows = d_points.download(np.uint64, m * 64).reshape(-1, 8)
-    pts = [O.from_affine(g.raw_to_affine(rows[i].tobytes())) for i in range(m)]
-    sc = [int.from_bytes(scalars[i].tobytes(), "little") for i in range(m)]
+    pts_jac = cref.aff_to_jac(cid, rows)
+    sc = np.ascontiguousarray(scalars[:m])
+    threads = host_threads()
     t0 = time.perf_counter()
-    ecarry, efns = dv.compute_lhs_witness(O, sc, pts, args.base)
+    st, ecarry, efns = cref.lhs_witness(sc, pts_jac, args.base, omega_raw, threads, decode=False)
     dt = time.perf_counter() - t0
-    ds = ctx.to_device(np.ascontiguousarray(scalars[:m]))
+    if st != 0:
+        raise SystemExit("CPU restatement of compute_lhs_witness failed on the sample (status %d)" % st)
+    st, ecarry, efns = cref.lhs_witness(sc, pts_jac, args.base, omega_raw, threads)      # again, decoded (untimed)
+    ds = ctx.to_device(sc)
     carry, index, out = ctx.lhs_witness_device(cid, ds.ptr, d_points.ptr, m, args.base, True)
     rinv = pow(1 << 256, -1, p)
-    from oracle import cref
-    if cref.jac_to_canonical(cid, np.ascontiguousarray(carry, np.uint64)) != g.canonical(O.to_affine(ecarry)):
+    if cref.jac_to_canonical(cid, np.ascontiguousarray(carry, np.uint64)) != cref.jac_to_canonical(cid, ecarry):
         raise SystemExit("GPU carry differs from the CPU oracle on the sample: parity broken")
     for f, exp in enumerate(efns):
         oa, la, ob, lb = (int(v) for v in index[f])
@@ -435,8 +440,8 @@ def cpu_baseline_lhs_witness(ctx, cid, scalars, d_points, args):
         gb = [int.from_bytes(r.tobytes(), "little") * rinv % p for r in _download_elems(ctx, out, ob, lb)]
         if (ga, gb) != e:
             raise SystemExit("GPU divisor witness %d differs from the CPU oracle on the sample: parity broken" % f)
-    return {"value": round(m / dt, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": "first 2^%d pairs of the same inputs, compute_lhs_witness restatement (oracle/divisor.py, Python big integers, serial), %.2f s, GPU result on the sample: carry and all %d functions equal" % (slog, dt, len(efns))}
+    return {"value": round(m / dt, 1), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "first 2^%d pairs of the same inputs, compute_lhs_witness restatement in C (oracle/c/witness_oracle.inc: the reference's products -- schoolbook below 32 coefficients, radix-2 FFT above -- with the %d merge trees spread over %d threads), %.2f s, GPU result on the sample: carry and all %d functions equal" % (slog, len(efns), threads, dt, len(efns))}
 
 
 def pmc_traffic(workload, curve, logn, world):

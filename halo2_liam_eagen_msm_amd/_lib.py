@@ -37,7 +37,7 @@ GRUMPKIN = 1
 # and that the built library exports each of them).
 SYMBOLS = [
     "lemsm_create", "lemsm_destroy", "lemsm_strerror", "lemsm_last_error", "lemsm_last_bad_index", "lemsm_last_truncated_count", "lemsm_set_option",
-    "lemsm_last_timing", "lemsm_last_accum_clock_mhz", "lemsm_debug_last_merge_counts",
+    "lemsm_last_timing", "lemsm_last_accum_clock_mhz", "lemsm_debug_last_merge_counts", "lemsm_debug_divisor_last_reuse_levels",
     "lemsm_msm", "lemsm_msm_bn254_g1", "lemsm_msm_grumpkin", "lemsm_msm_device",
     "lemsm_msm_plan", "lemsm_msm_partial_device", "lemsm_msm_combine",
     "lemsm_num_digits", "lemsm_negbase_decompose_batch",
@@ -98,6 +98,7 @@ def load() -> ctypes.CDLL:
         "lemsm_last_timing": (i, [vp, ctypes.POINTER(ctypes.c_double)]),
         "lemsm_last_accum_clock_mhz": (i, [vp, ctypes.POINTER(ctypes.c_double)]),
         "lemsm_debug_last_merge_counts": (i, [vp, ctypes.POINTER(ctypes.c_uint64)]),
+        "lemsm_debug_divisor_last_reuse_levels": (i, [vp, ctypes.POINTER(ctypes.c_uint32)]),
         "lemsm_msm": (i, [vp, i, u8p, u64p, sz, u64p]),
         "lemsm_msm_bn254_g1": (i, [vp, u8p, u64p, sz, u64p]),
         "lemsm_msm_grumpkin": (i, [vp, u8p, u64p, sz, u64p]),

@@ -202,6 +202,12 @@ class Context:
         self._check(self.lib.lemsm_last_timing(self.h, out))
         return out[0], out[1], int(out[2])
 
+    def divisor_last_reuse_levels(self) -> int:
+        """levels of the last divisor-witness forest that transformed onto the odd half of their domain only (test aid)"""
+        out = ctypes.c_uint32()
+        self._check(self.lib.lemsm_debug_divisor_last_reuse_levels(self.h, ctypes.byref(out)))
+        return out.value
+
     def last_merge_counts(self) -> Tuple[int, int, int, int]:
         """edge-record merge of the last MSM call: buckets queued as short (3..8 pieces), medium (9..32), slices of
         long ones, multi-slice buckets (test / profiling aid)"""
@@ -541,7 +547,7 @@ class Context:
 
     def debug_pointop(self, curve, op: int, acc_xyzz, q) -> np.ndarray:
         acc = _limbs(acc_xyzz, 16)
-        q = _limbs(q, 8 if op == 0 else 16)
+        q = _limbs(q, 16 if op == 1 else 8)
         out = np.zeros_like(acc)
         self._check(self.lib.lemsm_debug_pointop(self.h, _curve_id(curve), op, _ptr(acc), _ptr(q), _ptr(out), acc.shape[0]))
         return out

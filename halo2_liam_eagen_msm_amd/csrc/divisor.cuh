@@ -46,6 +46,10 @@ enum { STAT_MAXLEN = 0, STAT_PANIC = 1, STAT_ZERODEN = 2, STAT_MAXCHILD = 3, STA
 // what k_plan decides for one node of the next level
 struct Plan {
   u32 mode, la, lb, child0;  // child0: global index (level below) of the left child; the right one is child0 + 1
+  u32 evk[2];                // reuse mode (child-evaluation reuse, below): child 0 / 1's values on the even half of this level's domain
+                             // come from the level below's transform buffer (0: sequence = the child's node index) or from the
+                             // side buffer of passed-through children (1: sequence pair of this node's tree)
+  u32 tree;                  // tree index of this node
   u32 c0[8], c1[8], d0[8];   // line(-L.out, -R.out) = (c0 + c1 x) + y d0      (from_line(lx, ly, lz): a = [lz, lx], b = [ly], :244-246)
   u32 lX[8], lZZ[8], rX[8], rZZ[8];   // L.out, R.out as X / ZZ: the two kate_div points (:351-357) divide by (x - X/ZZ); here by
                                       // (ZZ x - X), a scalar multiple -- the witness is only defined up to a scalar anyway
@@ -98,9 +102,10 @@ struct Forest {
   u32 T;
 };
 // global node g -> (first child c0 as a global index of the level below, number of children 1 or 2 [0: none])
-__device__ __forceinline__ void locate(const Forest& f, u32 g, u32& c0, u32& nch) {
+__device__ __forceinline__ void locate(const Forest& f, u32 g, u32& c0, u32& nch, u32* tree = nullptr) {
   u32 lo = 0, hi = f.T;                      // largest t with off_node[t] <= g
   while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (f.off_node[mid] <= g) lo = mid; else hi = mid; }
+  if (tree) *tree = lo;
   const u32 k = g - f.off_node[lo];
   const u32 cb = f.off_child[lo], cn = f.off_child[lo + 1] - cb;
   c0 = cb + 2 * k;
@@ -192,12 +197,16 @@ __device__ __forceinline__ void rf_len(u32& la, u32& lb, u32 a1, u32 b1, u32 a2,
 }
 
 __global__ __launch_bounds__(256) void k_plan(const char* __restrict__ child_xyzz, const uint2* __restrict__ child_lens, Forest f, u32 nnodes,
-                                              const char* __restrict__ node_xyzz, Plan* __restrict__ plan, u32* __restrict__ stats) {
+                                              const char* __restrict__ node_xyzz, Plan* __restrict__ plan, u32* __restrict__ stats,
+                                              const Plan* __restrict__ prevplan /* the level below's plans (null at the first level): a child that was
+                                              passed through there has no evaluations on this level's even half */) {
   u32 k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nnodes) return;
   Plan pl;
-  u32 c0, nch; locate(f, k, c0, nch);
-  pl.child0 = c0;
+  u32 c0, nch, tree; locate(f, k, c0, nch, &tree);
+  pl.child0 = c0; pl.tree = tree;
+  pl.evk[0] = (prevplan && nch >= 1 && prevplan[c0].mode != MODE_PASS) ? 0u : 1u;
+  pl.evk[1] = (prevplan && nch >= 2 && prevplan[c0 + 1].mode != MODE_PASS) ? 0u : 1u;
   const u32 L = c0, R = c0 + 1;
   uint2 ll = child_lens[L];
   if (nch < 2) {                                      // MaybePair::Unit: passes through unchanged (:363-366)
@@ -282,6 +291,9 @@ __global__ __launch_bounds__(256) void k_ntt_stage(u32* __restrict__ buf, u32 ns
 struct TileIO {
   const u32* cA; const u32* cB; const uint2* child_lens; u32 ccapA, ccapB; const Plan* plan; u32 nnodes; const u32* GP; u32* c0in;      // load side
   u32* nA; u32* nB; u32 capA, capB; uint2* lens; const u32* GI; const u32* c0out; const u32* consts;                                      // store side
+  const u32* GO;       // reuse mode: (g omega_N)^i, i < N/2: the coset factors of the ODD half of this level's domain
+  const u32* exc;      // reuse mode: per tree, the child (global index of the level below) that was passed through there and is merged here, or ~0
+  u32 T;
 };
 // element g = (q * nnodes + k) * N + i of the forward input: coefficient i of child part q of node k, times g^i (k_load)
 __device__ __forceinline__ void tile_load_coeff(fe& v, const TileIO& io, u64 g, u32 logN) {
@@ -299,6 +311,58 @@ __device__ __forceinline__ void tile_load_coeff(fe& v, const TileIO& io, u64 g, 
   }
   if (io.c0in && i == 0) st(io.c0in + ((size_t)q * io.nnodes + k) * 8, v);
 }
+// ---- child-evaluation reuse -------------------------------------------------------------------------------------------
+// A node's forward transforms evaluate its children's polynomials on the coset g omega_N^j.  The even j are the
+// children's OWN domain (g omega_{N/2}^j'), where the level below has just evaluated exactly these polynomials -- its
+// quotient values sit in its transform buffer, in the same (bit-reversed) order as the first half of this level's slots.
+// So a level only transforms onto the ODD half of its domain: a size-N/2 transform of a_i (g omega_N)^i (a decimation in
+// frequency step with a zero upper half: the even half is DIF_{N/2}(a_i g^i), the odd half DIF_{N/2}(a_i (g omega_N)^i)),
+// half the butterflies and half the HBM passes of the forward transforms, a third of all transform work of a level.
+// A coefficient at index N/2 (wrap-mode children have N/2 + 1) folds onto index 0: +a_{N/2} g^{N/2} on the even half,
+// -a_{N/2} g^{N/2} on the odd.  A child that was passed through at the level below (the lone last node of a tree) has no
+// values there: its even half is transformed into a side buffer (two sequences per tree, tile_load_even_exc).
+// element g = (q * nnodes + k) * (N/2) + i of the odd-half input; logNh = log2(N/2)
+__device__ __forceinline__ void tile_load_odd(fe& v, const TileIO& io, u64 g, u32 logNh) {
+  const u64 per = (u64)io.nnodes << logNh;
+  const u32 q = (u32)(g / per); const u64 rem = g - (u64)q * per;
+  const u32 k = (u32)(rem >> logNh), i = (u32)rem & ((1u << logNh) - 1);
+  const u32 Nh = 1u << logNh;
+  F::set_zero(v);
+  if (io.plan[k].mode != MODE_PASS) {
+    const u32 c = io.plan[k].child0 + (q >> 1);
+    const uint2 cl = io.child_lens[c];
+    const u32 len = (q & 1) ? cl.y : cl.x;
+    const u32* src = (q & 1) ? io.cB + (size_t)c * io.ccapB * 8 : io.cA + (size_t)c * io.ccapA * 8;
+    if (i < len) ld(v, src + (size_t)i * 8);
+    if (io.c0in && i == 0) st(io.c0in + ((size_t)q * io.nnodes + k) * 8, v);          // p(0): the true constant term
+    if (i == 0) {
+      if (len > Nh) { fe top, gn; ld(top, src + (size_t)Nh * 8); ld(gn, io.consts + 56); F::mul(top, top, gn); F::sub(v, v, top); }   // a_0 - a_{N/2} g^{N/2}
+    } else if (i < len) { fe go; ld(go, io.GO + (size_t)i * 8); F::mul(v, v, go); }
+  } else if (io.c0in && i == 0) st(io.c0in + ((size_t)q * io.nnodes + k) * 8, v);
+}
+// element g = (2 t + part) * (N/2) + i of the side buffer: the passed-through child of tree t on the EVEN half
+__device__ __forceinline__ void tile_load_even_exc(fe& v, const TileIO& io, u64 g, u32 logNh) {
+  const u32 s = (u32)(g >> logNh), i = (u32)g & ((1u << logNh) - 1);
+  const u32 t = s >> 1, part = s & 1u, Nh = 1u << logNh;
+  F::set_zero(v);
+  if (t >= io.T) return;
+  const u32 c = io.exc[t];
+  if (c == 0xffffffffu) return;
+  const uint2 cl = io.child_lens[c];
+  const u32 len = part ? cl.y : cl.x;
+  const u32* src = part ? io.cB + (size_t)c * io.ccapB * 8 : io.cA + (size_t)c * io.ccapA * 8;
+  if (i < len) { ld(v, src + (size_t)i * 8); if (i) { fe gp; ld(gp, io.GP + (size_t)i * 8); F::mul(v, v, gp); } }
+  if (i == 0 && len > Nh) { fe top, gn; ld(top, src + (size_t)Nh * 8); ld(gn, io.consts + 56); F::mul(top, top, gn); F::add(v, v, top); }
+}
+// GO[i] = (g omega_N)^i = GP[i] * omega_N^i, i < N/2
+__global__ __launch_bounds__(256) void k_odd_factors(u32 logN, const u32* __restrict__ W, u32 log_half_max, const u32* __restrict__ GP, u32* __restrict__ GO) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (1u << (logN - 1))) return;
+  fe w, g; ld(w, W + ((size_t)i << (log_half_max + 1 - logN)) * 8); ld(g, GP + (size_t)i * 8);
+  F::mul(g, g, w);
+  st(GO + (size_t)i * 8, g);
+}
+
 // element g = (which * nnodes + k) * N + i of the inverse output -> coefficient i of part `which` of node k (k_store);
 // requires every length of the level <= N (N + 1 in wrap mode): the host checks STAT_MAXLEN / STAT_MAXPASS
 __device__ __forceinline__ void tile_store_coeff(const fe& t, const TileIO& io, u64 g, u32 logN) {
@@ -329,9 +393,12 @@ __device__ __forceinline__ void tile_store_coeff(const fe& t, const TileIO& io, 
   }
 }
 
-template <bool INV, int IO /* 0: buf -> buf; 1: the input is gathered from the coefficient arrays (fused k_load); 2: the output goes to the coefficient arrays (fused k_store) */>
+template <bool INV, int IO /* 0: src -> buf; 1: the input is gathered from the coefficient arrays (fused k_load); 2: the output goes to the coefficient
+                              arrays (fused k_store); 3 / 4: reuse mode, the odd half / a passed-through child's even half gathered from the coefficient arrays */>
 __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 total, u32 logN, u32 lo, u32 S,
-                                                  const u32* __restrict__ W, u32 log_half_max, TileIO io) {
+                                                  const u32* __restrict__ W, u32 log_half_max, TileIO io,
+                                                  const u32* __restrict__ src /* what a pass that does not gather reads: buf itself, or -- first pass of an
+                                                  out-of-place inverse transform -- the buffer whose values must survive */) {
   __shared__ u32 sm[8][1024];
   const u32 tid = threadIdx.x;
   const u32 TW = lo ? (1024u >> S) : 1u;            // lo > 0: TW tiles side by side; lo == 0: chunks of J inside 1024 contiguous
@@ -354,7 +421,12 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
     const u32 e = tid + 256u * q;
     const u64 g = gidx(e);
     fe v; F::set_zero(v);
-    if (g < total) { if (IO == 1) tile_load_coeff(v, io, g, logN); else ld(v, buf + g * 8); }
+    if (g < total) {
+      if (IO == 1) tile_load_coeff(v, io, g, logN);
+      else if (IO == 3) tile_load_odd(v, io, g, logN);
+      else if (IO == 4) tile_load_even_exc(v, io, g, logN);
+      else ld(v, src + g * 8);
+    }
 #pragma unroll
     for (int l = 0; l < 8; l++) sm[l][e] = v.v[l];
   }
@@ -519,7 +591,10 @@ __device__ __forceinline__ void pw_numerators(fe& A, fe& Bv, fe& den, bool divid
 __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
                                                 const u32* __restrict__ XS, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
                                                 u32* __restrict__ stats, u32* __restrict__ c0in /* wrap mode, else null; [3][k] receives the extra slot's denominator */,
-                                                u32* __restrict__ c0out) {
+                                                u32* __restrict__ c0out,
+                                                const u32* __restrict__ odd /* reuse mode (else null): the children on the odd half, [q][node][N/2] */,
+                                                const u32* __restrict__ evprev /* the level below's transform buffer: quotient values (times 1/(N/2)) on the even half */,
+                                                const u32* __restrict__ evexc /* passed-through children on the even half, [2 tree + part][N/2] */, u32 nn_prev) {
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 per = (u64)nnodes << logN;
@@ -540,7 +615,30 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
   fe x, sv, La, Lb, Ra, Rb, A, Bv, den;
   if (extra) { F::set_zero(x); ld(sv, consts); }                         // x = 0: 0^3 + b
   else { ld(x, XS + (size_t)i * 16); ld(sv, XS + (size_t)i * 16 + 8); }  // x_i, x_i^3 + b (= y^2)
-  ld(La, sLa); ld(Lb, sLb); ld(Ra, sRa); ld(Rb, sRb);
+  if (odd == nullptr || extra) { ld(La, sLa); ld(Lb, sLb); ld(Ra, sRa); ld(Rb, sRb); }
+  else {
+    const u32 logNh = logN - 1, Nh = N >> 1;
+    if (i >= Nh) {
+      const size_t perh = (size_t)nnodes << logNh;
+      const u32* o = odd + ((((size_t)k << logNh) + (i - Nh)) * 8);
+      ld(La, o); ld(Lb, o + perh * 8); ld(Ra, o + 2 * perh * 8); ld(Rb, o + 3 * perh * 8);
+    } else {
+      // even half: the children's own domain.  Values kept from the level below carry its 1/(N/2) (the scale of its inverse
+      // transform rode on the numerators): undone here through the scale of this level's numerators
+      u32 kept = 0;
+#pragma unroll
+      for (int side = 0; side < 2; side++) {
+        const u32* pa; const u32* pb;
+        if (pl.evk[side] == 0) { const u32 c = pl.child0 + side; pa = evprev + ((((size_t)c << logNh) + i) * 8); pb = pa + ((size_t)nn_prev << logNh) * 8; kept++; }
+        else { pa = evexc + (((size_t)(2 * pl.tree) << logNh) + i) * 8; pb = pa + ((size_t)1 << logNh) * 8; }
+        if (side == 0) { ld(La, pa); ld(Lb, pb); } else { ld(Ra, pa); ld(Rb, pb); }
+      }
+      if (kept) {
+        fe sc; ld(sc, consts + (kept == 2 ? 48 : 40));        // (N/2)^2 or N/2
+        if (divide) { F::mul(c0, c0, sc); F::mul(c1, c1, sc); F::mul(d0, d0, sc); } else F::mul(ninv, ninv, sc);
+      }
+    }
+  }
   pw_numerators(A, Bv, den, divide, x, sv, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, ninv);
   if (divide && F::is_zero(den)) { atomicOr(&stats[extra ? STAT_ZERO0 : STAT_ZERODEN], 1u); F::set_one(den); }
   if (extra) {

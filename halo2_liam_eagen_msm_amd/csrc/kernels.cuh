@@ -564,7 +564,7 @@ __global__ __launch_bounds__(1024) void k_binsort(GroupPlan pl, const u32* __res
 }
 
 // copy single points (task results that are already final, e.g. U_{L-1} = A^{L-1}[1])
-struct CopyTask { u32 src_off, src_wstride, dst_off, dst_wstride, src_valid_idx, src_idx; };
+// (struct CopyTask: plan.h)
 __global__ void k_copy_points(const CopyTask* __restrict__ tasks, u32 ntasks, u32 nwin, u32 pt_bytes, char* __restrict__ arena) {
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (task, window, 16-byte word)
   u32 wpp = pt_bytes / 16;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum1(GroupPlan pl, const u32* __
 // deterministic.
 // ------------------------------------------------------------------------------------
 enum { MQ_S = 0, MQ_M = 1, MQ_L = 2, MQ_F = 3, MQ_P = 4, MQ_WORDS = 16 /* [8..15]: debug cycle stamps of the wave kernels */ };   // queue counters: short, medium, long slices, multi-slice buckets, partials
-struct MqLayout { u32 offS, offM, offL, offF, capS, capM, capL, capF, capP, slice, wave_th; };
+// (struct MqLayout: plan.h)
 static const u32 MQ_DST_BUCKET = 0xffffffffu;
 
 template <class G>
@@ -345,14 +345,9 @@ __global__ __launch_bounds__(256) void k_merge_final(u32 scaled, MqLayout lay, c
 // read as the identity (padding of non-power-of-two bucket counts).
 // ------------------------------------------------------------------------------------
 // (layout of CopyTask in kernels.cuh)
-struct CopyTaskPod { u32 src_off, src_wstride, dst_off, dst_wstride, src_valid_idx, src_idx; };
+typedef CopyTask CopyTaskPod;   // (plan.h)
 
-struct PyrTask {
-  u32 src_off, src_wstride;   // per-window base = src_off + w * src_wstride
-  u32 dst_off, dst_wstride;
-  u32 stride, phase, count, src_valid;
-  u32 src_scaled, pad_[3];    // source is bucket_sum[] in the scaled form: convert on load
-};
+// (struct PyrTask: plan.h)
 
 // one item of one task: dst[i] = src[(2i) stride + phase] + src[(2i+1) stride + phase] for window w
 template <class G>

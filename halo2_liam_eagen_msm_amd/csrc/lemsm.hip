@@ -15,6 +15,7 @@
 #include "../../include/lemsm.h"
 #include "hostmath.hpp"
 #include "hostpool.hpp"
+#include "hosttail.hpp"
 #include <memory>
 #include "kernels.cuh"
 #include "rccl_dyn.hpp"
@@ -75,12 +76,6 @@ struct DevBuf {
 };
 
 
-// bucket-reduction pyramid: per step a list of pairwise-add tasks (kernels_ec.cuh)
-struct PyrPlan {
-  std::vector<std::vector<PyrTask>> steps;   // steps[s-1] for s = 1..L
-  std::vector<u32> step_max_count;
-  CopyTask copy;                              // U_{L-1} = A^{L-1}[1]
-};
 struct PyrCacheEntry { DevBuf buf; PyrPlan pp; };   // task tables resident on the device
 
 }  // namespace
@@ -101,9 +96,10 @@ struct lemsm_ctx {
   DevBuf in_p;      // staged points
   DevBuf in_aux;    // staged Jacobian points / misc
   DevBuf gather;    // multi-GPU: all ranks' raw per-window records after the all-gather
+  DevBuf fail_buf;  // multi-GPU: the zeroed stand-in a rank sends when its own pipeline failed before the exchange
   DevBuf dw_tab, dw_arena, dw_tmp;   // divisor witness: twiddle / coset tables, level workspace, tmp point list
   u32 dw_logn = 0, dw_gexp = 0;      // tables hold transforms up to 2^dw_logn with coset generator 7^dw_gexp
-  double dw_ntt_ms = 0; u64 dw_ntt_bytes = 0, dw_ntt_bflies = 0;
+  double dw_ntt_ms = 0; u64 dw_ntt_bytes = 0, dw_ntt_bflies = 0; u32 dw_reuse_levels = 0;
   double dw_phase_ms[4] = {0, 0, 0, 0};   // lhs witness: MSM core, point lists, merge forest, coefficient download
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
@@ -112,7 +108,7 @@ struct lemsm_ctx {
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
   long opt_host_threads = 0;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -274,72 +270,6 @@ MsmPlan make_msm_plan(const lemsm_ctx* ctx, int curve, size_t n) {
 
 template <class F> struct FieldTag {};
 
-// ---- pyramid task tables ----
-
-// arena offsets (in points) for one group
-struct ArenaLayout {
-  u32 bucket_off, apyr_off, rbuf_off, out_off, total_points;
-};
-
-ArenaLayout make_arena(u32 NBpad, u32 nbp, u32 gw, u32 L) {
-  ArenaLayout a;
-  a.bucket_off = 0;
-  a.apyr_off = NBpad;
-  a.rbuf_off = a.apyr_off + nbp * gw;
-  a.out_off = a.rbuf_off + nbp * gw;
-  a.total_points = a.out_off + (L + 1) * gw;
-  return a;
-}
-
-PyrPlan make_pyr_plan(const ArenaLayout& ar, u32 nb, u32 nbw, u32 nbp, u32 L, bool scaled /* bucket_sum[] holds (X, Y, 32 ZZ, 32 ZZZ) */) {
-  PyrPlan pp;
-  auto offA = [&](u32 l) { return nbp - (nbp >> (l - 1)); };                    // level l >= 1 inside a window's A region
-  auto offR = [&](u32 l, u32 j) { u32 rs = nbp >> (l + 1); return (nbp - (nbp >> l)) + (rs - (rs >> (j - 1))); };
-  auto srcA = [&](u32 l, PyrTask& t) {    // A^l as a source
-    if (l == 0) { t.src_off = ar.bucket_off; t.src_wstride = nbw; t.src_valid = nb; t.src_scaled = scaled ? 1u : 0u; }
-    else { t.src_off = ar.apyr_off + offA(l); t.src_wstride = nbp; t.src_valid = nbp >> l; }
-  };
-  for (u32 s = 1; s <= L; s++) {
-    std::vector<PyrTask> tasks;
-    PyrTask t; memset(&t, 0, sizeof t);
-    srcA(s - 1, t);
-    t.stride = 1; t.phase = 0; t.count = nbp >> s;
-    if (s == L) { t.dst_off = ar.out_off; t.dst_wstride = L + 1; }
-    else { t.dst_off = ar.apyr_off + offA(s); t.dst_wstride = nbp; }
-    tasks.push_back(t);
-    if (s + 1 <= L) {
-      u32 cnt = nbp >> (s + 1);
-      for (u32 l = 0; l < s; l++) {
-        u32 j = s - l;
-        PyrTask r; memset(&r, 0, sizeof r);
-        if (j == 1) { srcA(l, r); r.stride = 2; r.phase = 1; }
-        else { r.src_off = ar.rbuf_off + offR(l, j - 1); r.src_wstride = nbp; r.src_valid = nbp >> (l + j); r.stride = 1; r.phase = 0; }
-        r.count = cnt;
-        if (cnt == 1) { r.dst_off = ar.out_off + 1 + l; r.dst_wstride = L + 1; }
-        else { r.dst_off = ar.rbuf_off + offR(l, j); r.dst_wstride = nbp; }
-        tasks.push_back(r);
-      }
-    }
-    if (L == 1 && scaled) {
-      // one level only: U_0 = bucket[1] is read through a task (bucket[1] + nothing) instead of the
-      // copy below, because only tasks convert the scaled form on load
-      PyrTask r; memset(&r, 0, sizeof r);
-      srcA(0, r); r.stride = 1; r.phase = 1; r.count = 1; r.src_valid = std::min(r.src_valid, 2u);
-      r.dst_off = ar.out_off + 1; r.dst_wstride = L + 1;
-      tasks.push_back(r);
-    }
-    pp.step_max_count.push_back(nbp >> s);
-    pp.steps.push_back(tasks);
-  }
-  // U_{L-1} = A^{L-1}[1]
-  memset(&pp.copy, 0, sizeof pp.copy);
-  if (L == 1) { pp.copy.src_off = ar.bucket_off; pp.copy.src_wstride = nbw; pp.copy.src_valid_idx = nb; }
-  else { pp.copy.src_off = ar.apyr_off + offA(L - 1); pp.copy.src_wstride = nbp; pp.copy.src_valid_idx = 2; }
-  pp.copy.src_idx = 1;
-  pp.copy.dst_off = ar.out_off + L; pp.copy.dst_wstride = L + 1;
-  return pp;
-}
-
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Workspace carve for one window group.
@@ -361,18 +291,9 @@ struct GroupWs {
   std::vector<size_t> guards;      // option ws_canary: offsets of the 256-byte guard behind every sub-buffer
 };
 
-// merge queues of one group (kernels_ec.cuh "edge-record merge").  A bucket of P >= 2 pieces spans P chunks and
-// neighbouring buckets share at most one chunk, so at most nthr1 / (P - 1) buckets have P or more pieces.
 MqLayout make_mq_layout(const lemsm_ctx* ctx, u32 nthr1) {
-  MqLayout m; memset(&m, 0, sizeof m);
-  m.slice = ctx && ctx->opt_merge_slice ? (u32)ctx->opt_merge_slice : 512u;      // pieces per wave of a long bucket
-  m.wave_th = ctx && ctx->opt_merge_wave_th ? (u32)ctx->opt_merge_wave_th - 1u : 2048u;   // 9..32-piece buckets: one wave each up to this many, serial beyond
-  m.capS = nthr1 / 2 + 2; m.capM = nthr1 / 8 + 2;
-  m.capF = nthr1 / m.slice + 2;                  // buckets of more than one slice
-  m.capL = nthr1 / 32 + nthr1 / m.slice + 4;     // slices: sum ceil(P / slice) over buckets of > 32 pieces
-  m.capP = 2 * (nthr1 / m.slice) + 4;            // partial sums (multi-slice buckets only)
-  m.offS = 0; m.offM = m.offS + m.capS; m.offL = m.offM + m.capM; m.offF = m.offL + m.capL;
-  return m;
+  return make_mq_layout_t(nthr1, ctx && ctx->opt_merge_slice ? (u32)ctx->opt_merge_slice : 512u,
+                          ctx && ctx->opt_merge_wave_th ? (u32)ctx->opt_merge_wave_th - 1u : 2048u);
 }
 
 const size_t WS_GUARD = 256;
@@ -727,71 +648,45 @@ size_t group_ws_bytes(const lemsm_ctx* ctx, const GroupPlan& pl, u32 nbp, u32 L,
 
 // Generic windowed bucket pipeline over window range [wb,we): fills host_out with
 // (we-wb) x (L+1) XYZZ points, summed over slabs.
-// Device records -> host XYZZ points (x*2^256 Montgomery, canonical).
-// strict arithmetic: records already are 4 x 32-byte canonical x*2^256 values.
-// lazy arithmetic: records are 36 raw signed 29-bit limbs of x*2^261 representatives with
-// |V| < 8N: add 8N, carry-normalise, reduce mod N, then multiply by 2^-5 (montmul by 2^251).
-template <class P64>
-host::fe reduce_raw29(const int32_t* l) {
-  typedef host::HF<P64> F;
-  // N as 29-bit limbs
-  int64_t v[9];
-  u64 n29[9];
-  for (int i = 0; i < 9; i++) {
-    int bit = 29 * i, wi = bit >> 6, sh = bit & 63;
-    u64 lo = P64::N[wi] >> sh;
-    u64 hi = (sh + 29 > 64 && wi + 1 < 4) ? (P64::N[wi + 1] << (64 - sh)) : 0;
-    n29[i] = (lo | hi) & ((1ULL << 29) - 1);
-  }
-  int64_t c = 0;
-  for (int i = 0; i < 9; i++) {
-    int64_t t = (int64_t)l[i] + (int64_t)(n29[i] << 3) + c;   // + 8N limb-wise (limbs may exceed 29 bits; carried below)
-    if (i < 8) { v[i] = t & ((1LL << 29) - 1); c = t >> 29; } else v[i] = t;
-  }
-  // pack the non-negative value (< 16N < 2^258) into 5 x u64
-  u64 w[5] = {0, 0, 0, 0, 0};
-  for (int i = 0; i < 9; i++) {   // limbs are disjoint bit fields now: OR them in
-    int bit = 29 * i, wi = bit >> 6, sh = bit & 63;
-    w[wi] |= (u64)v[i] << sh;
-    if (sh + 29 > 64 && wi + 1 < 5) w[wi + 1] |= (u64)v[i] >> (64 - sh);
-  }
-  // reduce below N by subtracting N while >= N (at most 16 times)
-  for (int it = 0; it < 20; it++) {
-    bool ge = w[4] != 0;
-    if (!ge) { ge = true; for (int i = 3; i >= 0; i--) { if (w[i] > P64::N[i]) break; if (w[i] < P64::N[i]) { ge = false; break; } } }
-    if (!ge) break;
-    u64 bw = 0;
-    for (int i = 0; i < 5; i++) { unsigned __int128 d = (unsigned __int128)w[i] - (i < 4 ? P64::N[i] : 0) - bw; w[i] = (u64)d; bw = (u64)(d >> 64) & 1; }
-  }
-  host::fe r; for (int i = 0; i < 4; i++) r.l[i] = w[i];
-  host::fe k251 = {{0, 0, 0, 0x0800000000000000ULL}};   // 2^251 (< N): montmul(a, 2^251) = a * 2^-5
-  return F::mul(r, k251);
-}
-
-template <class P64, class G>
-void from_device_records(const char* raw, size_t n, host::pt* out) {
-  if constexpr (!G::CONVERTED_DOMAIN) {
-    memcpy(out, raw, n * sizeof(host::pt));
-  } else {
-    for (size_t i = 0; i < n; i++) {
-      const int32_t* l = reinterpret_cast<const int32_t*>(raw + i * G::PT_BYTES);
-      bool zz_zero = true;
-      for (int k = 0; k < 9; k++) zz_zero &= (l[18 + k] == 0);
-      if (zz_zero) { memset(&out[i], 0, sizeof(host::pt)); continue; }
-      out[i].x = reduce_raw29<P64>(l); out[i].y = reduce_raw29<P64>(l + 9);
-      out[i].zz = reduce_raw29<P64>(l + 18); out[i].zzz = reduce_raw29<P64>(l + 27);
-    }
-  }
-}
 
 // One call's raw per-window records on the device: nslabs blocks of out_slab bytes, block k holding the
 // records [total, U_0..U_{L-1}] of windows wb.. of slab k (nw_pad windows' worth of room, unused tail zeroed).
 struct WinRun {
   size_t nslabs = 0, ng = 0, out_slab = 0, SLAB = 0, err_slot = 0;
+  size_t err_stride = 1;   // status slots per slab: nw_pad, the same on every rank whatever its own number of window groups
+  size_t err_cap = 0;      // bytes of the status-slot area (nslabs x err_stride slots, rounded up)
   char* d_out = nullptr; char* d_err = nullptr;
   u32 nw = 0, nw_pad = 0, L = 0; size_t ptb = 0;
   size_t send_bytes() const { return out_slab * nslabs; }
+  // multi-GPU: what one rank contributes to the all-gather -- its records, its status slots (so that every rank sees every
+  // rank's non-canonical-scalar flags and all return the same status) and one 256-byte rank status (STATUS_BYTES)
+  static constexpr size_t STATUS_BYTES = 256;
+  size_t send_total() const { return out_slab * nslabs + err_cap + STATUS_BYTES; }
 };
+
+// The part of run_windows_enqueue's bookkeeping that fixes what a rank sends in the exchange (device-pointer entries):
+// a function of the call's arguments and options alone, the same on every rank.
+template <class G>
+void win_sizes(const lemsm_ctx* ctx, size_t n, u32 nw_pad, u32 L, WinRun& wr) {
+  const u32 slab_log = ctx->opt_slab_bits ? (u32)ctx->opt_slab_bits : MAX_SLAB_LOG;
+  wr.SLAB = (size_t)1 << slab_log;
+  wr.nslabs = n ? (n + wr.SLAB - 1) / wr.SLAB : 1;
+  wr.ptb = G::PT_BYTES; wr.L = L; wr.nw_pad = nw_pad; wr.nw = 0; wr.ng = 0;
+  wr.out_slab = align_up((size_t)std::max(nw_pad, 1u) * (L + 1) * wr.ptb, 256);
+  wr.err_slot = 96; wr.err_stride = std::max<size_t>(nw_pad, 1);
+  wr.err_cap = align_up(wr.nslabs * wr.err_stride * wr.err_slot, 256);
+  wr.d_out = nullptr; wr.d_err = nullptr;
+}
+
+// A rank that cannot take part in a collective its peers may already be waiting in tears the communicator down, so that
+// they return LEMSM_ERR_RCCL instead of blocking for ever (ncclCommAbort; the communicator is unusable afterwards).
+void comm_abort(lemsm_ctx* ctx) {
+  if (!ctx->comm) return;
+  Rccl& rc = Rccl::get();
+  if (rc.CommAbort) (void)rc.CommAbort(ctx->comm); else (void)rc.CommDestroy(ctx->comm);
+  ctx->comm = nullptr; ctx->comm_size = 1; ctx->comm_rank = 0;
+  ctx->last_error += " [communicator aborted: this rank could not enter the exchange]";
+}
 
 // Enqueues the whole pipeline of one call (every slab, every window group) on the context's queues and leaves the
 // raw records in the workspace (wr.d_out); nothing is read back.  nw_pad >= we - wb sizes the record area per slab
@@ -838,17 +733,20 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   }
   const size_t ng = groups.size();
   const size_t out_slab = align_up((size_t)std::max(nw_pad, 1u) * (L + 1) * ptb, 256);   // one slab's records
-  const size_t ERR_SLOT = 96;   // per (slab, group): err[2] of the digit pass, then k_accum1's clock stamps (4 x u64) at byte 16
-  const size_t err_bytes = align_up(std::max<size_t>(nslabs * ng, 1) * ERR_SLOT, 256);
+  const size_t ERR_SLOT = 96;   // (win_sizes: the same) per (slab, group): err[2] of the digit pass, then k_accum1's clock stamps (4 x u64) at byte 16
+  const size_t err_stride = std::max<size_t>(nw_pad, 1);      // slot (slab k, group gi) = k * err_stride + gi, gi < ng <= nw <= nw_pad
+  const size_t err_bytes = align_up(nslabs * err_stride * ERR_SLOT, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
-  int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nslabs + err_bytes + 4096);
+  // sizes first (a rank that fails below still has to contribute a buffer of the agreed size to the collective)
+  wr.nslabs = nslabs; wr.ng = ng; wr.out_slab = out_slab; wr.SLAB = SLAB; wr.err_slot = ERR_SLOT; wr.err_stride = err_stride; wr.err_cap = err_bytes;
+  wr.nw = nw; wr.nw_pad = nw_pad; wr.L = L; wr.ptb = ptb;
+  int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nslabs + err_bytes + WinRun::STATUS_BYTES + 4096);
   if (rc) return rc;
   char* ws_base = (char*)ctx->ws.p;
   char* d_conv = ws_base + ws_total;
   char* d_out = d_conv + conv_bytes;
   char* d_err = d_out + out_slab * nslabs;
-  wr.nslabs = nslabs; wr.ng = ng; wr.out_slab = out_slab; wr.SLAB = SLAB; wr.err_slot = ERR_SLOT;
-  wr.d_out = d_out; wr.d_err = d_err; wr.nw = nw; wr.nw_pad = nw_pad; wr.L = L; wr.ptb = ptb;
+  wr.d_out = d_out; wr.d_err = d_err;
   while (ctx->evpool.size() < 3 * ng * nslabs + (hs ? nslabs : 0)) {
     hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e);
   }
@@ -863,6 +761,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
   if (nw_pad != nw || n == 0 || nw == 0)      // record slots no kernel writes (a rank with fewer windows than the widest one) read as identities
     HIPCHK(ctx, hipMemsetAsync(d_out, 0, out_slab * nslabs, s_acc));
+  HIPCHK(ctx, hipMemsetAsync(d_err, 0, err_bytes + WinRun::STATUS_BYTES, s_acc));   // status slots no group writes, and the rank status word (0 = ok)
   for (size_t k = 0; k < nslabs && n && nw; k++) {
     const size_t s0 = k * SLAB;
     u32 sn = (u32)std::min(SLAB, n - s0);
@@ -912,7 +811,7 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
       auto src = make_src(s0, sn);
       hipEvent_t* ev = ctx->evpool.data() + 3 * (k * ng + gi);
       rc = run_group<G>(ctx, src, pl, nbp, L, pts, abi, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
-                        (u32*)(d_err + (k * ng + gi) * ERR_SLOT), s_sort, s_acc, s_tail, ev[0], ev[1], ev[2], gi == 0 ? ev_points : nullptr);
+                        (u32*)(d_err + (k * err_stride + gi) * ERR_SLOT), s_sort, s_acc, s_tail, ev[0], ev[1], ev[2], gi == 0 ? ev_points : nullptr);
       if (rc) return rc;
     }
     if (!one_queue) {   // three queues share one workspace: drain before the next slab reuses it
@@ -929,16 +828,48 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
 // The queue the records of run_windows_enqueue become final on (where a collective or the read-back is enqueued).
 hipStream_t records_stream(const lemsm_ctx* ctx) { return ctx->opt_groups <= 1 ? ctx->stream : ctx->stream_tail; }
 
-// Reads back `raw_bytes` of records from d_raw (wr.d_out, or the gathered buffer of a multi-GPU call) and this call's
-// error / clock words, waits, and turns the digit pass's flags into the reference's panic sites.
+// This rank's own bookkeeping out of its status slots (host copy `slots`, wr.err_cap bytes): merge-queue counters, clock
+// stamps and accumulate timings of the last call.
+int collect_local_stats(lemsm_ctx* ctx, const WinRun& wr, const u32* slots) {
+  u64 clk_cyc = 0, clk_ticks = 0;
+  const size_t sw = wr.err_slot / 4;
+  for (int q = 0; q < 4; q++) ctx->dbg_merge[q] = 0;
+  for (size_t k = 0; k < wr.nslabs; k++)
+    for (size_t gi = 0; gi < wr.ng; gi++) {
+      const u32* ew = slots + (k * wr.err_stride + gi) * sw;
+      const size_t i = k * wr.ng + gi;             // the events of (slab, group) are numbered densely
+      for (int q = 0; q < 4; q++) ctx->dbg_merge[q] += ew[12 + q];
+      for (int q = 0; q < 8; q++) ctx->dbg_stamps[q] = ew[16 + q];
+      float a = 0; HIPCHK(ctx, hipEventElapsedTime(&a, ctx->evpool[3 * i + 1], ctx->evpool[3 * i + 2]));
+      ctx->t_accum_ms += a; ctx->n_accum++;
+      u64 ck[4]; memcpy(ck, ew + 4, 32);
+      if (ck[2] > ck[0] && ck[3] > ck[1] && ck[2] - ck[0] < ((u64)1 << 40)) { clk_cyc += ck[2] - ck[0]; clk_ticks += ck[3] - ck[1]; }
+    }
+  ctx->accum_clock_mhz = clk_ticks ? (double)clk_cyc / (double)clk_ticks * 100.0 : 0.0;
+  return LEMSM_OK;
+}
+
+// Non-canonical scalars (>= field order) are rejected, never bucketed: the smallest offending index over the status slots
+// of one rank's area (all nslabs x err_stride slots: unused ones are zero), or SIZE_MAX.
+size_t first_bad_scalar(const WinRun& wr, const u32* slots) {
+  size_t best = SIZE_MAX;
+  const size_t sw = wr.err_slot / 4;
+  for (size_t k = 0; k < wr.nslabs; k++)
+    for (size_t gi = 0; gi < wr.err_stride; gi++) {
+      const u32* ew = slots + (k * wr.err_stride + gi) * sw;
+      if (ew[0]) best = std::min(best, k * wr.SLAB + (size_t)(~ew[1]));
+    }
+  return best;
+}
+
+// Reads back this call's records (wr.d_out) together with its status slots, waits, and turns the digit pass's flags into
+// the reference's panic sites.  raw_bytes = 0: the status slots only (one-GPU rehearsal of a rank).
 int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size_t raw_bytes, std::vector<char>& raw) {
   hipStream_t s_tail = records_stream(ctx);
   raw.resize(raw_bytes);
-  const size_t nerr = wr.nslabs * wr.ng;
-  std::vector<u32> errw(std::max<size_t>(nerr, 1) * (wr.err_slot / 4));
-  // read-back through the context's pinned buffer: records and error words sit next to each other in the workspace,
-  // so a single-GPU call is ONE asynchronous copy (pageable destinations made two staged copies with ~25 us gaps)
-  const size_t err_bytes = nerr * wr.err_slot;
+  const size_t err_bytes = wr.ng ? wr.err_cap : 0;
+  // read-back through the context's pinned buffer: records and status slots sit next to each other in the workspace,
+  // so a call is ONE asynchronous copy (pageable destinations made two staged copies with ~25 us gaps)
   { int rcp = reserve_pinned(ctx, raw_bytes + err_bytes + 64); if (rcp) return rcp; }
   char* hp = (char*)ctx->h_pin;
   if (d_raw == wr.d_out && raw_bytes == wr.send_bytes() && raw_bytes + err_bytes) {
@@ -952,39 +883,22 @@ int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size
   HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
   ctx->host_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
   if (raw_bytes) memcpy(raw.data(), hp, raw_bytes);
-  if (err_bytes) memcpy(errw.data(), hp + raw_bytes, err_bytes);
   float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
   ctx->t_total_ms = ms;
-  for (size_t k = 0; k < wr.nslabs; k++)   // non-canonical scalars (>= field order) are rejected, never bucketed
-    for (size_t gi = 0; gi < wr.ng; gi++) {
-      const u32* ew = errw.data() + (k * wr.ng + gi) * (wr.err_slot / 4);
-      if (ew[0]) {
-        ctx->bad_index = k * wr.SLAB + (size_t)(~ew[1]);
-        return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
-      }
-    }
-  u64 clk_cyc = 0, clk_ticks = 0;
-  for (int q = 0; q < 4; q++) ctx->dbg_merge[q] = 0;
-  for (size_t i = 0; i < nerr; i++) {
-    for (int q = 0; q < 4; q++) ctx->dbg_merge[q] += errw[i * (wr.err_slot / 4) + 12 + q];
-    for (int q = 0; q < 8; q++) ctx->dbg_stamps[q] = errw[i * (wr.err_slot / 4) + 16 + q];
-    float a = 0; HIPCHK(ctx, hipEventElapsedTime(&a, ctx->evpool[3 * i + 1], ctx->evpool[3 * i + 2]));
-    ctx->t_accum_ms += a; ctx->n_accum++;
-    u64 ck[4]; memcpy(ck, errw.data() + i * (wr.err_slot / 4) + 4, 32);
-    if (ck[2] > ck[0] && ck[3] > ck[1] && ck[2] - ck[0] < ((u64)1 << 40)) { clk_cyc += ck[2] - ck[0]; clk_ticks += ck[3] - ck[1]; }
+  if (!err_bytes) return LEMSM_OK;
+  std::vector<u32> slots(err_bytes / 4);
+  memcpy(slots.data(), hp + raw_bytes, err_bytes);
+  const size_t bad = first_bad_scalar(wr, slots.data());
+  if (bad != SIZE_MAX) {
+    ctx->bad_index = bad;
+    return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
   }
-  ctx->accum_clock_mhz = clk_ticks ? (double)clk_cyc / (double)clk_ticks * 100.0 : 0.0;
-  return LEMSM_OK;
+  return collect_local_stats(ctx, wr, slots.data());
 }
 
-// S_w = total + sum_l 2^l U_l  for one window record [total, U_0..U_{L-1}]
-template <class P64>
-host::pt window_sum(const host::pt* rec, u32 L) {
-  typedef host::HG<P64> G;
-  host::pt acc = G::identity();
-  for (int l = (int)L - 1; l >= 0; l--) { acc = G::dbl(acc); acc = G::add(acc, rec[1 + l]); }
-  return G::add(acc, rec[0]);
-}
+
+template <class P64, class G>
+void from_device_records(const char* raw, size_t n, host::pt* out) { from_device_records_t<P64, G::CONVERTED_DOMAIN, G::PT_BYTES>(raw, n, out); }
 
 // host: records of nw windows = sum over the slabs of one rank's record area (raw: nslabs blocks of out_slab bytes)
 template <class P64, class G>
@@ -1034,23 +948,7 @@ void window_sums_par(lemsm_ctx* ctx, const host::pt* recs /* nw x (L+1) */, u32 
 }
 
 template <class P64>
-void msm_combine_t(const MsmPlan& mp, const host::pt* recs /* W window sums */, u64 out[12]) {
-  typedef host::HG<P64> G;
-  host::pt acc = G::identity();
-  for (int w = (int)mp.W - 1; w >= 0; w--) {
-    for (u32 k = 0; k < mp.c; k++) acc = G::dbl(acc);
-    acc = G::add(acc, recs[w]);
-  }
-  G::to_jacobian(acc, out);
-}
-
-template <class P64>
-void jacobian_sum_t(const uint64_t* jac, size_t count, uint64_t out[12]) {
-  typedef host::HG<P64> G;
-  host::pt acc = G::identity();
-  for (size_t i = 0; i < count; i++) acc = G::add(acc, G::from_jacobian(jac + 12 * i));
-  G::to_jacobian(acc, out);
-}
+void msm_combine_t(const MsmPlan& mp, const host::pt* sums /* W window sums */, u64 out[12]) { msm_combine_windows<P64>(mp.c, mp.W, sums, out); }
 
 template <class P64, class G>
 int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, u32 wb, u32 we,
@@ -1148,20 +1046,8 @@ int lhs_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   return LEMSM_OK;
 }
 
-// carries: MSB-first Horner with multiplier -base over per-position sums (src/argument_witness_calc.rs:105-127)
 template <class P64>
-void lhs_combine_t(const LhsPlan& lp, const host::pt* recs /* d per-position sums S_i, LSB-first position order */, u64 out_carry[12],
-                   u64* out_carries) {
-  typedef host::HG<P64> G;
-  host::pt carry = G::identity();
-  for (u32 it = 0; it < lp.d; it++) {
-    u32 pos = lp.d - 1 - it;
-    carry = G::mul_small(G::neg(carry), lp.base);                                  // :118
-    carry = G::add(carry, recs[pos]);                                              // :120-125
-    if (out_carries) G::to_jacobian(carry, out_carries + 12 * (size_t)it);
-  }
-  G::to_jacobian(carry, out_carry);
-}
+void lhs_combine_t(const LhsPlan& lp, const host::pt* sums, u64 out_carry[12], u64* out_carries) { lhs_combine_positions<P64>(lp.base, lp.d, sums, out_carry, out_carries); }
 
 // field selection: option "field" 0 = lazy radix-2^29 (default), 1 = strict 32-bit limbs
 int msm_partial_dispatch(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* d_points, size_t n, u32 wb, u32 we,
@@ -1192,6 +1078,7 @@ int lhs_partial_dispatch(lemsm_ctx* ctx, int curve, const void* d_scalars, const
 // run one after the other on this GPU and their record areas are copied into the gathered buffer where the
 // collective would have put them, so everything but the ncclAllGather call itself is exercised.
 struct Exchange { int world, rank; bool sim; };
+int validate_points(lemsm_ctx* ctx, int curve, const void* d_points, size_t n);   // (defined below)
 
 #define RCCLCHK(ctx, expr)                                                                     \
   do {                                                                                         \
@@ -1202,35 +1089,72 @@ struct Exchange { int world, rank; bool sim; };
     }                                                                                          \
   } while (0)
 
-inline void shard_range(u32 W, int world, int r, u32& a, u32& b) {
-  a = (u32)((u64)W * (u64)r / (u64)world); b = (u32)((u64)W * (u64)(r + 1) / (u64)world);
-}
 
 // shared by the MSM and the lhs path: runs the rank's (or, simulated, every rank's) windows and returns the records of
 // ALL W windows (W x (L+1) host points, slabs summed)
 template <class P64, class G, class MakeSrc>
 int sharded_records(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 nbp, u32 L, u32 W, u32 d, const void* d_points,
-                    const Exchange& ex, std::vector<host::pt>& all) {
+                    const Exchange& ex, std::vector<host::pt>& all, int rc_pre = LEMSM_OK /* a failure of this rank before the pipeline */) {
   u32 max_nw = 0;
   for (int r = 0; r < ex.world; r++) { u32 a, b; shard_range(W, ex.world, r, a, b); max_nw = std::max(max_nw, b - a); }
   WinRun wr; std::vector<char> raw;
   size_t sb = 0;
   if (!ex.sim) {
+    // Collective-safe: whatever happens on this rank before the exchange -- a failed allocation, a plan over a kernel
+    // limit, rejected input points (rc_pre) -- it still contributes a buffer of the agreed size, zeroed, with its status
+    // in the rank status word, and every rank learns of the failure from the gathered buffer; no rank is left waiting in
+    // ncclAllGather.  Only when not even that stand-in can be had is the communicator aborted (peers then return
+    // LEMSM_ERR_RCCL).  The status slots travel too: every rank sees every rank's non-canonical-scalar flags, so all ranks
+    // return the same status -- also a rank without windows of its own (world > W), which runs no digit pass.
     u32 a, b; shard_range(W, ex.world, ex.rank, a, b);
-    int rc = run_windows_enqueue<P64, G>(ctx, make_src, n, c, nb, nbp, L, W, a, b, d, d_points, max_nw, wr);
-    if (rc) return rc;
-    sb = wr.send_bytes();
-    rc = reserve(ctx, ctx->gather, sb * ex.world); if (rc) return rc;
-    RCCLCHK(ctx, Rccl::get().AllGather(wr.d_out, ctx->gather.p, sb, ncclUint8, ctx->comm, records_stream(ctx)));
-    rc = run_windows_finish(ctx, wr, (const char*)ctx->gather.p, sb * ex.world, raw);
-    if (rc) return rc;
+    int rc_local = rc_pre;
+    if (!rc_local) rc_local = run_windows_enqueue<P64, G>(ctx, make_src, n, c, nb, nbp, L, W, a, b, d, d_points, max_nw, wr);
+    else win_sizes<G>(ctx, n, max_nw, L, wr);      // the sizes every rank agrees on, without touching the device
+    sb = wr.send_total();
+    hipStream_t st = records_stream(ctx);
+    const char* send = wr.d_out;
+    if (rc_local) {
+      if (reserve(ctx, ctx->fail_buf, sb) != LEMSM_OK) { comm_abort(ctx); return rc_local; }
+      HIPCHK(ctx, hipMemsetAsync(ctx->fail_buf.p, 0, sb, st));
+      HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)((char*)ctx->fail_buf.p + sb - WinRun::STATUS_BYTES), rc_local, 1, st));
+      send = (const char*)ctx->fail_buf.p;
+    }
+    if (reserve(ctx, ctx->gather, sb * ex.world) != LEMSM_OK) { comm_abort(ctx); return rc_local ? rc_local : LEMSM_ERR_NOMEM; }
+    {
+      ncclResult_t r_ = Rccl::get().AllGather(send, ctx->gather.p, sb, ncclUint8, ctx->comm, st);
+      if (r_ != ncclSuccess) { ctx->last_error = std::string("ncclAllGather: ") + Rccl::get().GetErrorString(r_); comm_abort(ctx); return LEMSM_ERR_RCCL; }
+    }
+    // one read-back of the whole gathered buffer
+    { int rcp = reserve_pinned(ctx, sb * ex.world + 64); if (rcp) return rcp; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->gather.p, sb * ex.world, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[1]));
+    const char* hp = (const char*)ctx->h_pin;
+    std::vector<u32> status(ex.world);
+    for (int r = 0; r < ex.world; r++) memcpy(&status[r], hp + (size_t)r * sb + sb - WinRun::STATUS_BYTES, 4);
+    int failed_rank = -1;
+    const int agreed = merge_rank_status(status.data(), ex.world, ex.rank, rc_local, &failed_rank);
+    if (agreed != LEMSM_OK) {
+      if (agreed != rc_local || !rc_local) ctx->last_error = "rank " + std::to_string(failed_rank) + " failed before the exchange with status " + std::to_string(status[failed_rank]) + " (" + lemsm_strerror((int)status[failed_rank]) + ")";
+      return agreed;
+    }
+    float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->t_total_ms = ms;
+    size_t bad = SIZE_MAX;
+    for (int r = 0; r < ex.world; r++) bad = std::min(bad, first_bad_scalar(wr, (const u32*)(hp + (size_t)r * sb + wr.send_bytes())));
+    if (bad != SIZE_MAX) {
+      ctx->bad_index = bad;
+      return fail(ctx, LEMSM_ERR_SCALAR_OUT_OF_RANGE, "scalar is not a canonical field element (>= order)");
+    }
+    { int rcs = collect_local_stats(ctx, wr, (const u32*)(hp + (size_t)ex.rank * sb + wr.send_bytes())); if (rcs) return rcs; }
+    raw.assign(hp, hp + sb * ex.world);
   } else {
     double t_total = 0, t_acc = 0; int n_acc = 0;
     for (int r = 0; r < ex.world; r++) {
       u32 a, b; shard_range(W, ex.world, r, a, b);
       int rc = run_windows_enqueue<P64, G>(ctx, make_src, n, c, nb, nbp, L, W, a, b, d, d_points, max_nw, wr);
       if (rc) return rc;
-      sb = wr.send_bytes();
+      sb = wr.send_total();      // records + status slots + rank status, as the collective moves them
       if (r == 0) { rc = reserve(ctx, ctx->gather, sb * ex.world); if (rc) return rc; }
       HIPCHK(ctx, hipMemcpyAsync((char*)ctx->gather.p + (size_t)r * sb, wr.d_out, sb, hipMemcpyDeviceToDevice, records_stream(ctx)));
       std::vector<char> none;
@@ -1261,7 +1185,9 @@ int msm_sharded_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
     memcpy(s.kadd.k, mp.kadd, 32); memcpy(s.kadd.order, order_of(curve), 32); return s;
   };
   std::vector<host::pt> all;
-  int rc = sharded_records<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, 0, d_points, ex, all);
+  // (a rank whose input check fails still enters the exchange: sharded_records carries rc_pre to every rank)
+  const int rc_pre = validate_points(ctx, curve, d_points, n);
+  int rc = sharded_records<P64, G>(ctx, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, 0, d_points, ex, all, rc_pre);
   if (rc) return rc;
   std::vector<host::pt> sums;
   window_sums_par<P64>(ctx, all.data(), mp.W, mp.L, sums);
@@ -1275,12 +1201,13 @@ int lhs_sharded_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   if (n >= ((size_t)1 << 32)) return fail(ctx, LEMSM_ERR_BAD_ARG, "n too large");
   u32 pb = 0, pe = lp.d;
   if (!ex.sim) shard_range(lp.d, ex.world, ex.rank, pb, pe);
-  LhsDigits dg;
-  int rc = lhs_digits(ctx, curve, d_scalars, n, lp, ctx->in_aux, dg, pb, pe);   // every rank range-checks every scalar; it stores its own rows only
-  if (rc) return rc;
+  LhsDigits dg; dg.digitsT = nullptr; dg.err = nullptr;
+  // a failure before the exchange (input check, digit buffer) is carried into it, never returned ahead of the peers
+  int rc_pre = validate_points(ctx, curve, d_points, n);
+  if (!rc_pre) rc_pre = lhs_digits(ctx, curve, d_scalars, n, lp, ctx->in_aux, dg, pb, pe);   // every rank range-checks every scalar; it stores its own rows only
   auto make_src = [&](size_t s0, u32) { NegProvider s; s.digitsT = dg.digitsT + s0; return s; };
   std::vector<host::pt> all;
-  rc = sharded_records<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, lp.d, d_points, ex, all);
+  int rc = sharded_records<P64, G>(ctx, make_src, n, 0, lp.nb, lp.nbp, lp.L, lp.d, lp.d, d_points, ex, all, rc_pre);
   if (rc) return rc;
   u32 err[2];
   { int rce = lhs_err_words(ctx, n, err); if (rce) return rce; }
@@ -1415,6 +1342,69 @@ __global__ __launch_bounds__(256) void k_gen_walk(const uint4* __restrict__ q_af
   }
 }
 
+// ---- known-answer entries for the DEFAULT arithmetic (option field = 0): the lazy radix-2^29 field and its XYZZ law,
+// reached directly instead of only through whole-MSM results.  Inputs and outputs keep the C ABI's form (x * 2^256,
+// canonical): a value enters the lazy field through from_abi (x * 2^261, normalised) and leaves through div32 + canon.
+template <class F29>
+__device__ __forceinline__ void dbg_in29(typename F29::fe& r, const void* p) { typename F29::fe a; F29::load(a, p); F29::from_abi(r, a); }
+template <class F29>
+__device__ __forceinline__ void dbg_out29(void* p, const typename F29::fe& a) { typename F29::fe t; F29::div32(t, a); F29::store(p, t); }
+
+// op 0: add, 1: sub, 2: neg(a), 4: sqr(a), 5: mul2 = a*b + b*a, 6: sqr_addhi = a^2 + b, 7: mul_addhi = a*b + b, 8: mul (as lemsm_debug_montmul),
+// 9: mul32 / from_abi round trip = a (x -> 32x lazily, then back)
+template <class F29>
+__global__ void k_dbg_fieldop29(int op, const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  typename F29::fe x, y, r;
+  dbg_in29<F29>(x, a + 2 * (size_t)i); dbg_in29<F29>(y, b + 2 * (size_t)i);
+  if (op == 0) { F29::add(r, x, y); F29::wnorm(r); }
+  else if (op == 1) F29::sub(r, x, y);
+  else if (op == 2) F29::neg(r, x);
+  else if (op == 4) F29::sqr(r, x);
+  else if (op == 5) F29::mul2(r, x, y, y, x);
+  else if (op == 6) F29::sqr_addhi(r, x, y);
+  else if (op == 7) F29::mul_addhi(r, x, y, y);
+  else if (op == 9) { typename F29::fe c; F29::load(c, a + 2 * (size_t)i); F29::mul32(r, c); }   // canonical x*2^256 -> lazy x*2^261
+  else F29::mul(r, x, y);
+  dbg_out29<F29>(out + 2 * (size_t)i, r);
+}
+// op 3: the inversion every batched-inversion kernel uses (inv_lazy: Fermat in the lazy field on a strict element)
+template <class F>
+__global__ void k_dbg_inv_lazy(const uint4* __restrict__ a, uint4* __restrict__ out, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  typename F::fe x, r; F::load(x, a + 2 * (size_t)i);
+  inv_via_lazy<F>(r, x);
+  F::store(out + 2 * (size_t)i, r);
+}
+// op 0: XYZZ29::madd, 1: add, 2: madd_abi (accumulator in the scaled form, incoming point as the ABI passes it)
+template <class G29>
+__global__ void k_dbg_pointop29(int op, const char* __restrict__ acc_in, const char* __restrict__ q_in, char* __restrict__ out, u32 n) {
+  typedef typename G29::F_ F29;
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  typename G29::pt acc;
+  const char* ap = acc_in + (size_t)i * 128;
+  dbg_in29<F29>(acc.x, ap); dbg_in29<F29>(acc.y, ap + 32); dbg_in29<F29>(acc.zz, ap + 64); dbg_in29<F29>(acc.zzz, ap + 96);
+  if (G29::is_identity(acc)) G29::set_identity(acc);
+  if (op == 0 || op == 2) {
+    typename F29::fe xa, ya; F29::load(xa, q_in + (size_t)i * 64); F29::load(ya, q_in + (size_t)i * 64 + 32);
+    if (!(F29::limbs_zero(xa) && F29::limbs_zero(ya))) {
+      if (op == 0) { typename F29::fe x, y; F29::from_abi(x, xa); F29::from_abi(y, ya); G29::madd(acc, x, y); }
+      else { G29::scale(acc); bool empty = G29::is_identity(acc); G29::madd_abi(acc, xa, ya, empty); G29::unscale(acc); }
+    }
+  } else {
+    typename G29::pt q; const char* qp = q_in + (size_t)i * 128;
+    dbg_in29<F29>(q.x, qp); dbg_in29<F29>(q.y, qp + 32); dbg_in29<F29>(q.zz, qp + 64); dbg_in29<F29>(q.zzz, qp + 96);
+    if (G29::is_identity(q)) G29::set_identity(q);
+    G29::add(acc, q);
+  }
+  char* op_ = out + (size_t)i * 128;
+  if (G29::is_identity(acc)) { uint4 z = make_uint4(0, 0, 0, 0); for (int k = 0; k < 8; k++) reinterpret_cast<uint4*>(op_)[k] = z; return; }
+  dbg_out29<F29>(op_, acc.x); dbg_out29<F29>(op_ + 32, acc.y); dbg_out29<F29>(op_ + 64, acc.zz); dbg_out29<F29>(op_ + 96, acc.zzz);
+}
+
 // optional input validation (option "validate_points"): every affine point is (0,0) or satisfies y^2 = x^3 + b
 template <class F>
 __global__ __launch_bounds__(256) void k_validate_points(const uint4* __restrict__ pts, u32 n, int bcoef /* +3 or -17 */, u32* __restrict__ err) {
@@ -1513,7 +1503,7 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   ctx->pool.reset();
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->h_small) (void)hipHostFree(ctx->h_small);
-  for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather, &ctx->dw_tab, &ctx->dw_arena, &ctx->dw_tmp}) if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather, &ctx->fail_buf, &ctx->dw_tab, &ctx->dw_arena, &ctx->dw_tmp}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1539,6 +1529,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "ws_canary")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_ws_canary = value; }
   else if (!strcmp(name, "dw_kb")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_kb = value; }
   else if (!strcmp(name, "dw_fuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_fuse = value; }
+  else if (!strcmp(name, "dw_reuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_reuse = value; }
   else if (!strcmp(name, "dw_wrap")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_wrap = value; }
   else if (!strcmp(name, "ntt_tiled")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_ntt_tiled = value; }
   else if (!strcmp(name, "pyr_fuse")) { if (value < 0 || value > 2) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_fuse = value; }
@@ -1918,7 +1909,7 @@ int lemsm_debug_lhs_sharded_sim(lemsm_ctx* ctx, int curve, const void* d_scalars
 }
 
 // ---- resident bases (halo2's bases are a fixed SRS: upload once, then only scalars cross PCIe) ------------------
-struct lemsm_bases { lemsm_ctx* ctx; int curve; size_t n; void* d_points; };
+struct lemsm_bases { lemsm_ctx* ctx; int device; int curve; size_t n; void* d_points; bool validated; };   // `device` kept here: the context may be gone when the bases are freed
 
 int lemsm_bases_upload(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, size_t n, lemsm_bases** out) {
   if (!ctx || !out || (n && !points_affine)) return LEMSM_ERR_BAD_ARG;
@@ -1929,12 +1920,14 @@ int lemsm_bases_upload(lemsm_ctx* ctx, int curve, const uint64_t* points_affine,
   hipError_t e = hipMalloc(&d, n ? n * 64 : 64);
   if (e != hipSuccess) return fail(ctx, LEMSM_ERR_NOMEM, hipGetErrorString(e));
   if (n) { e = hipMemcpy(d, points_affine, n * 64, hipMemcpyHostToDevice); if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, LEMSM_ERR_HIP, hipGetErrorString(e)); } }
-  *out = new lemsm_bases{ctx, curve, n, d};
+  // option validate_points: resident bases are checked ONCE, here, not on every call that uses them
+  if (ctx->opt_validate_points) { rc = validate_points(ctx, curve, d, n); if (rc) { (void)hipFree(d); return rc; } }
+  *out = new lemsm_bases{ctx, ctx->device, curve, n, d, ctx->opt_validate_points != 0};
   return LEMSM_OK;
 }
 void lemsm_bases_free(lemsm_bases* b) {
   if (!b) return;
-  (void)hipSetDevice(b->ctx->device);
+  (void)hipSetDevice(b->device);              // (never through b->ctx: a host may destroy the context first)
   (void)hipFree(b->d_points);
   delete b;
 }
@@ -1950,7 +1943,10 @@ int lemsm_msm_with_bases(lemsm_ctx* ctx, const lemsm_bases* bases, const uint8_t
   int rc = reserve(ctx, ctx->in_s, n * 32); if (rc) return rc;
   HostStage hs{scalars, nullptr, (char*)ctx->in_s.p, (char*)bases->d_points};
   ctx->host_stage = &hs;
+  const long saved_validate = ctx->opt_validate_points;
+  if (bases->validated) ctx->opt_validate_points = 0;   // checked at upload
   rc = lemsm_msm_device(ctx, bases->curve, ctx->in_s.p, bases->d_points, n, out);
+  ctx->opt_validate_points = saved_validate;
   ctx->host_stage = nullptr;
   return rc;
 }
@@ -2058,8 +2054,11 @@ int lemsm_node_msm(lemsm_node* nd, const uint8_t* scalars, size_t n, uint64_t ou
   if (nd->curve < 0) { nd->last_error = "lemsm_node_set_bases first"; return LEMSM_ERR_BAD_ARG; }
   if (n > nd->n_bases) { nd->last_error = "more scalars than resident bases"; return LEMSM_ERR_LEN_MISMATCH; }
   std::vector<uint64_t> outs((size_t)nd->ctx.size() * 12);
-  int rc = node_parallel(nd, [&](int i) -> int {
-    int r = node_stage_scalars(nd, i, scalars, n); if (r) return r;
+  // phase 1, no collective: every GPU stages the scalars; any failure ends the call before a rank could be left waiting
+  int rc = node_parallel(nd, [&](int i) -> int { return node_stage_scalars(nd, i, scalars, n); });
+  if (rc) return rc;
+  // phase 2: the collective call (itself collective-safe: sharded_records)
+  rc = node_parallel(nd, [&](int i) -> int {
     return lemsm_msm_sharded_device(nd->ctx[i], nd->curve, nd->d_scalars[i], nd->d_points[i], n, outs.data() + 12 * (size_t)i);
   });
   if (rc) return rc;
@@ -2077,8 +2076,9 @@ int lemsm_node_lhs_msm(lemsm_node* nd, const uint8_t* scalars, size_t n, uint8_t
   const size_t G = nd->ctx.size();
   std::vector<uint64_t> carry(G * 12), carries(out_carries ? G * 12 * d : 0);
   std::vector<size_t> bad(G, 0);
+  rc = node_parallel(nd, [&](int i) -> int { return node_stage_scalars(nd, i, scalars, n); });   // phase 1, no collective
+  if (rc) return rc;
   rc = node_parallel(nd, [&](int i) -> int {
-    int r = node_stage_scalars(nd, i, scalars, n); if (r) return r;
     return lemsm_lhs_msm_sharded_device(nd->ctx[i], nd->curve, nd->d_scalars[i], nd->d_points[i], n, base, carry.data() + 12 * (size_t)i,
                                         out_carries ? carries.data() + (size_t)i * 12 * d : nullptr, &bad[i]);
   });
@@ -2231,7 +2231,10 @@ int lemsm_debug_montmul(lemsm_ctx* ctx, int curve, const uint64_t* a, const uint
   char *da, *db, *dout;
   rc = dbg_run3(ctx, a, n * 32, b, n * 32, n * 32, &da, &db, &dout); if (rc) return rc;
   dim3 g((u32)((n + 255) / 256)), blk(256);
-  if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_montmul<FqDev>), g, blk, 0, ctx->stream, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  if (ctx->opt_field == 0) {   // the hot kernels' default arithmetic
+    if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_fieldop29<Field29<Fq29Params>>), g, blk, 0, ctx->stream, 8, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+    else hipLaunchKernelGGL((k_dbg_fieldop29<Field29<Fr29Params>>), g, blk, 0, ctx->stream, 8, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  } else if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_montmul<FqDev>), g, blk, 0, ctx->stream, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
   else hipLaunchKernelGGL((k_dbg_montmul<FrDev>), g, blk, 0, ctx->stream, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -2247,7 +2250,14 @@ int lemsm_debug_fieldop(lemsm_ctx* ctx, int curve, int op, const uint64_t* a, co
   char *da, *db, *dout;
   rc = dbg_run3(ctx, a, n * 32, b, n * 32, n * 32, &da, &db, &dout); if (rc) return rc;
   dim3 g((u32)((n + 255) / 256)), blk(256);
-  if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_fieldop<FqDev>), g, blk, 0, ctx->stream, op, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  if (ctx->opt_field == 0 && op == 3) {
+    if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_inv_lazy<FqDev>), g, blk, 0, ctx->stream, (const uint4*)da, (uint4*)dout, (u32)n);
+    else hipLaunchKernelGGL((k_dbg_inv_lazy<FrDev>), g, blk, 0, ctx->stream, (const uint4*)da, (uint4*)dout, (u32)n);
+  } else if (ctx->opt_field == 0) {
+    if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_fieldop29<Field29<Fq29Params>>), g, blk, 0, ctx->stream, op, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+    else hipLaunchKernelGGL((k_dbg_fieldop29<Field29<Fr29Params>>), g, blk, 0, ctx->stream, op, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
+  } else if (op > 4) return fail(ctx, LEMSM_ERR_BAD_ARG, "field ops 5..9 exist in the lazy field only (option field = 0)");
+  else if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_fieldop<FqDev>), g, blk, 0, ctx->stream, op, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
   else hipLaunchKernelGGL((k_dbg_fieldop<FrDev>), g, blk, 0, ctx->stream, op, (const uint4*)da, (const uint4*)db, (uint4*)dout, (u32)n);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -2260,12 +2270,16 @@ int lemsm_debug_pointop(lemsm_ctx* ctx, int curve, int op, const uint64_t* acc, 
   int rc = check_curve(ctx, curve); if (rc) return rc;
   if (!n) return LEMSM_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  size_t qb = op == 0 ? 64 : 128;
+  if (op < 0 || op > 2) return fail(ctx, LEMSM_ERR_BAD_ARG, "point op: 0 madd, 1 add, 2 madd_abi");
+  size_t qb = op == 1 ? 128 : 64;
   char *da, *db, *dout;
   rc = dbg_run3(ctx, acc, n * 128, q, n * qb, n * 128, &da, &db, &dout); if (rc) return rc;
   dim3 g((u32)((n + 63) / 64)), blk(64);
-  if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_pointop<FqDev>), g, blk, 0, ctx->stream, op, da, db, dout, (u32)n);
-  else hipLaunchKernelGGL((k_dbg_pointop<FrDev>), g, blk, 0, ctx->stream, op, da, db, dout, (u32)n);
+  if (ctx->opt_field == 0) {
+    if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_pointop29<GqLazy>), g, blk, 0, ctx->stream, op, da, db, dout, (u32)n);
+    else hipLaunchKernelGGL((k_dbg_pointop29<GrLazy>), g, blk, 0, ctx->stream, op, da, db, dout, (u32)n);
+  } else if (curve == LEMSM_BN254_G1) hipLaunchKernelGGL((k_dbg_pointop<FqDev>), g, blk, 0, ctx->stream, op == 2 ? 0 : op, da, db, dout, (u32)n);
+  else hipLaunchKernelGGL((k_dbg_pointop<FrDev>), g, blk, 0, ctx->stream, op == 2 ? 0 : op, da, db, dout, (u32)n);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(out, dout, n * 128, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -37,4 +37,19 @@ struct GroupPlan {
   uint32_t nstride;  // negabase: row stride of the digit matrix = points of the WHOLE call (a slab sees a column range of it)
 };
 
+// Bucket-reduction pyramid: one task of one step (kernels_ec.cuh: k_pyramid), plain data shared by the host's plan
+// builder (hosttail.hpp) and the kernels.  dst[i] = src[(2i) stride + phase] + src[(2i+1) stride + phase], i < count, for
+// every window; arena offsets are in points; src indices >= src_valid read as the identity.
+struct PyrTask {
+  uint32_t src_off, src_wstride;   // per-window base = src_off + w * src_wstride
+  uint32_t dst_off, dst_wstride;
+  uint32_t stride, phase, count, src_valid;
+  uint32_t src_scaled, pad_[3];    // source is bucket_sum[] in the scaled form: convert on load
+};
+// copy of a single point per window (task results that are already final, e.g. U_{L-1} = A^{L-1}[1])
+struct CopyTask { uint32_t src_off, src_wstride, dst_off, dst_wstride, src_valid_idx, src_idx; };
+
+// Edge-record merge queues (kernels_ec.cuh): item offsets and capacities of one window group
+struct MqLayout { uint32_t offS, offM, offL, offF, capS, capM, capL, capF, capP, slice, wave_th; };
+
 }  // namespace lemsm

@@ -18,6 +18,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;    // optional: absent -> CommDestroy
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -50,7 +51,10 @@ struct Rccl {
           r.sym(r.CommDestroy, "ncclCommDestroy") && r.sym(r.AllGather, "ncclAllGather") &&
           r.sym(r.Broadcast, "ncclBroadcast") && r.sym(r.GetErrorString, "ncclGetErrorString"))) {
       dlclose(r.handle); r.handle = nullptr;
-    } else r.error.clear();
+    } else {
+      r.CommAbort = reinterpret_cast<ncclResult_t (*)(ncclComm_t)>(dlsym(r.handle, "ncclCommAbort"));
+      r.error.clear();
+    }
     return r;
   }
 };

@@ -106,7 +106,8 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    stage: A/B knob), "dw_kb" (divisor witness: slots per thread of the batched-inversion kernels, 8..64; 0 = auto),
    "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
    input from the coefficient arrays and the last inverse pass scatters into them; 2 = separate load / store kernels:
-   A/B knob), "dw_wrap" (divisor witness: 0 = levels whose longest part
+   A/B knob), "dw_reuse" (divisor witness: 0 = a level transforms its children onto the odd half of its domain only and reads the even half from the level
+   below's evaluations, 2 = whole transforms: A/B knob), "dw_wrap" (divisor witness: 0 = levels whose longest part
    has 2^k + 1 coefficients run on 2^k-point transforms, the folded top coefficient recovered from the value at x = 0;
    2 = always the next power of two: A/B knob), "ws_canary" (1 = debug: every sub-buffer of the MSM workspace is followed by a 256-byte guard that is
    filled before and verified after every window group; an overrun returns LEMSM_ERR_HIP naming the guard; the fuzz
@@ -278,6 +279,9 @@ int lemsm_divisor_witness_device(lemsm_ctx* ctx, int curve, const void* d_points
 int lemsm_divisor_witness_batch(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, const size_t* counts, size_t T,
                                 int require_zero_sum, int normalise, uint64_t* out_coeffs, size_t cap_coeffs,
                                 size_t* out_index, uint64_t* out_points_affine);
+/* Test / profiling aid: levels of the last divisor-witness forest whose forward transforms covered only the odd half of the
+   level's domain, the even half being the level below's own evaluations (child-evaluation reuse; option "dw_reuse" 2 = off). */
+int lemsm_debug_divisor_last_reuse_levels(const lemsm_ctx* ctx, uint32_t* levels);
 /* Device time (ms) of the transform launches of the last divisor-witness call (with option dw_fuse at its default the
    first forward and the last inverse pass of a level also gather from / scatter into the coefficient arrays), their algorithmic bytes (every element
    read once and written once per pass over HBM: 1 pass up to 2^10 elements, 2 up to 2^18, 3 beyond) and their butterfly
@@ -354,6 +358,13 @@ int lemsm_device_download(lemsm_ctx* ctx, void* dst, const void* src, size_t byt
 int lemsm_device_gen_walk(lemsm_ctx* ctx, int curve, const uint64_t q_affine[8], size_t n, void* d_points_out);
 
 /* ---- debug / known-answer hooks used by the parity tests ----------------------------- */
+/* Raw Montgomery limbs (x * 2^256, canonical) in and out.  montmul: out = a*b*R^-1.  fieldop: 0 add, 1 sub, 2 neg(a),
+   3 inverse(a) (Montgomery inverse), 4 sqr(a).  pointop: 0 = madd(acc XYZZ, q affine), 1 = add(acc XYZZ, q XYZZ),
+   2 = madd_abi (the accumulate kernel's second form; an alias of 0 in the strict arithmetic).
+   They run the arithmetic option "field" selects: 0, the default, is the lazy radix-2^29 field of the hot kernels
+   (Field29 / XYZZ29; values enter through from_abi and leave through div32 + canon; op 3 is inv_lazy, the inversion of
+   every batched-inversion kernel); 1 is the strict 32-bit-limb field.  Lazy field only: fieldop 5 = mul2(a, b, b, a) =
+   2ab/R, 6 = sqr_addhi = a^2/R + b, 7 = mul_addhi = ab/R + b, 9 = mul32 round trip = a. */
 int lemsm_debug_montmul(lemsm_ctx* ctx, int curve, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int lemsm_debug_fieldop(lemsm_ctx* ctx, int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int lemsm_debug_pointop(lemsm_ctx* ctx, int curve, int op, const uint64_t* acc_xyzz, const uint64_t* q,

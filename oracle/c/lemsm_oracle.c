@@ -570,3 +570,6 @@ int orc_msm_naive(int cid, const uint8_t *scalars, const u64 *bases_aff, size_t 
     }
     memcpy(out_jac, &total, 96); return ORC_OK;
 }
+
+/* compiled, threaded restatement of the divisor-witness path (compute_lhs_witness in full): see the file */
+#include "witness_oracle.inc"

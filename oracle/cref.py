@@ -14,7 +14,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liblemsm_oracle.so")
+# LEMSM_ORACLE_LIB: an alternative build of the same source, e.g. `make -C oracle asan` run under LD_PRELOAD=libasan (tests/test_host_logic.py)
+_LIB_PATH = os.environ.get("LEMSM_ORACLE_LIB") or os.path.join(_HERE, "_build", "liblemsm_oracle.so")
 
 ORC_OK, ORC_LEN_MISMATCH, ORC_SCALAR_OUT_OF_RANGE, ORC_BAD_BASE, ORC_BAD_CURVE = 0, 1, 2, 3, 4
 
@@ -233,3 +234,62 @@ def aff_to_jac(cid: int, pts_aff: np.ndarray) -> np.ndarray:
     nonid = np.any(pts_aff != 0, axis=1)
     out[nonid, 8:12] = R
     return out
+
+
+# ---- compiled, threaded restatement of the divisor-witness path (oracle/c/witness_oracle.inc) ----------------------
+_R_INV = {}
+
+
+def _from_mont_list(raw: np.ndarray, p: int):
+    """(k, 4) raw Montgomery limbs -> list of canonical Python ints"""
+    if p not in _R_INV:
+        _R_INV[p] = pow(1 << 256, -1, p)
+    ri = _R_INV[p]
+    b = np.ascontiguousarray(raw, np.uint64).tobytes()
+    return [int.from_bytes(b[32 * i:32 * i + 32], "little") * ri % p for i in range(len(b) // 32)]
+
+
+def divisor_witness(pts_jac: np.ndarray, omega0_mont: np.ndarray, threads: int = 1):
+    """compute_divisor_witness over Grumpkin (regular_functions_utils.rs:476-480) -> (status, a, b): status 0 ok,
+    1 = the points do not sum to the identity, 2 = the reference's usize underflow; a, b = coefficient lists (canonical ints)"""
+    pts = np.ascontiguousarray(pts_jac, np.uint64).reshape(-1, 12)
+    n = pts.shape[0]
+    cap = 2 * n + 16
+    coeffs = np.zeros((cap, 4), np.uint64)
+    la = ctypes.c_size_t(); lb = ctypes.c_size_t()
+    fn = lib().orc_divisor_witness
+    fn.argtypes = [_u64p, ctypes.c_size_t, _u64p, ctypes.c_int, _u64p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    st = fn(_p64(pts), n, _p64(np.ascontiguousarray(omega0_mont, np.uint64)), threads, _p64(coeffs), cap, ctypes.byref(la), ctypes.byref(lb))
+    if st == 3:
+        raise ValueError("divisor_witness: coefficient buffer too small")
+    p = int.from_bytes(field_consts(1)[0].tobytes(), "little")
+    vals = _from_mont_list(coeffs[:la.value + lb.value], p)
+    return st, vals[:la.value], vals[la.value:]
+
+
+def lhs_witness(scalars: np.ndarray, pts_jac: np.ndarray, base: int, omega0_mont: np.ndarray, threads: int = 1, decode: bool = True):
+    """compute_lhs_witness over Grumpkin (argument_witness_calc.rs:87-136) -> (status, carry (12 limbs), [(a, b)] per returned
+    function); decode=False skips the conversion of the coefficients to Python ints (timing runs) and returns the lengths"""
+    sc = np.ascontiguousarray(scalars, np.uint8).reshape(-1, 32)
+    pts = np.ascontiguousarray(pts_jac, np.uint64).reshape(-1, 12)
+    n = sc.shape[0]
+    d, _ = num_digits(1, base)
+    cap = d * (n + base + 8) + 64
+    coeffs = np.zeros((cap, 4), np.uint64)
+    lens = np.zeros(2 * d, np.uint64)
+    carry = np.zeros(12, np.uint64)
+    fn = lib().orc_lhs_witness
+    fn.argtypes = [_u8p, _u64p, ctypes.c_size_t, ctypes.c_uint8, _u64p, ctypes.c_int, _u64p, _u64p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    st = fn(_p8(sc), _p64(pts), n, base, _p64(np.ascontiguousarray(omega0_mont, np.uint64)), threads, _p64(carry), _p64(coeffs), cap,
+            lens.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)))
+    if st == 3:
+        raise ValueError("lhs_witness: coefficient buffer too small")
+    if not decode:
+        return st, carry, [(int(lens[2 * f]), int(lens[2 * f + 1])) for f in range(d)]
+    p = int.from_bytes(field_consts(1)[0].tobytes(), "little")
+    out = []; off = 0
+    for f in range(d):
+        la, lb = int(lens[2 * f]), int(lens[2 * f + 1])
+        vals = _from_mont_list(coeffs[off:off + la + lb], p)
+        out.append((vals[:la], vals[la:])); off += la + lb
+    return st, carry, out

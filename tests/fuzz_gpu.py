@@ -107,6 +107,22 @@ def scalar_witness_case(rng, ctx, seed, cases):
     base = int(rng.choice([3, 5, 16, 17, 255])); nd = int(rng.integers(1, 60)); lt = int(rng.integers(1, 20))
     vals = [int(rng.integers(0, 1 << 62)) << int(rng.integers(0, 66)) for _ in range(40)]
     vals = [v if rng.random() < 0.7 else -v for v in vals]
+    if rng.random() < 0.55:
+        # Half of the cases are drawn where the reference does NOT panic (uniform parameters panic almost always:
+        # `i % logtable + 1` leaves the row as soon as logtable^2 exceeds num_digits, and (-base)^i leaves i128 from
+        # i ~ 127 / log2(base)): logtable^2 <= num_digits, magnitudes of at most min(num_digits, i128 range) digits
+        import math
+        for _ in range(20):
+            lt = int(rng.integers(1, 6)); nd = int(rng.integers(lt * lt, 60))
+            maxdig = max(1, min(nd, int(126 / math.log2(base))) - 1)
+            vals = [int(rng.integers(0, 1 << 62)) % (base ** int(rng.integers(1, maxdig + 1))) for _ in range(40)]
+            vals = [v if rng.random() < 0.7 else -v for v in vals]
+            try:
+                for v in vals:
+                    pyref.prepare_scalar_witness(v, base, nd, lt)
+                break
+            except pyref.RefPanic:
+                continue
     sc = np.frombuffer(b"".join(abs(v).to_bytes(32, "little") for v in vals), np.uint8).reshape(-1, 32)
     neg = np.array([1 if v < 0 else 0 for v in vals], np.uint8)
     first = None; kinds = []
@@ -146,7 +162,7 @@ def main(secs=None, seed=None):
     head = int.from_bytes(bytes.fromhex(chains["omega_pow"]["head"]), "little")
     O = dv.DivisorOracle(pyref.GRUMPKIN, dv.FrFft(pyref.GRUMPKIN.fp, head * pow(1 << 256, -1, pyref.GRUMPKIN.fp) % pyref.GRUMPKIN.fp))
     t0 = time.time(); cases = 0; kinds_seen = {}
-    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "merge_slice", "merge_wave_th", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows", "ws_canary", "pyr_fuse", "pyr_first2", "binsort", "dw_wrap", "dw_fuse"]
+    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "merge_slice", "merge_wave_th", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows", "ws_canary", "pyr_fuse", "pyr_first2", "binsort", "dw_wrap", "dw_fuse", "dw_reuse"]
     while time.time() - t0 < secs:
         curve = CURVES[int(rng.integers(0, 2))]
         opts = {"window_bits": int(rng.choice([0, 0, 2, 3, 5, 8, 11, 13, 16, 17])), "chunk": int(rng.choice([0, 0, 1, 3, 17, 64, 300])),
@@ -155,7 +171,7 @@ def main(secs=None, seed=None):
                 "accum_waves": int(rng.choice([0, 0, 2, 4])), "host_slab_bits": int(rng.choice([0, 12, 13, 16])),
                 "groups": 0, "entry_ring": int(rng.integers(0, 2)), "xcd_windows": int(rng.integers(0, 2)),
                 "ws_canary": int(rng.random() < 0.3), "pyr_fuse": int(rng.choice([0, 0, 1, 2])), "pyr_first2": int(rng.random() < 0.3),
-                "binsort": int(rng.choice([0, 0, 2, 3, 40, 700])), "dw_wrap": int(rng.choice([0, 0, 2])), "dw_fuse": int(rng.choice([0, 0, 2]))}     # 2: tiled pass 2 only; > 2: a bin capacity that splits the bins between both paths
+                "binsort": int(rng.choice([0, 0, 2, 3, 40, 700])), "dw_wrap": int(rng.choice([0, 0, 2])), "dw_fuse": int(rng.choice([0, 0, 2])), "dw_reuse": int(rng.choice([0, 0, 2]))}     # 2: tiled pass 2 only; > 2: a bin capacity that splits the bins between both paths
         host_entry = rng.random() < 0.5
         if not host_entry:
             opts["groups"] = int(rng.choice([0, 0, 2, 3]))     # pipelined window groups: device-pointer entries only

@@ -73,4 +73,4 @@ def test_bench_lhs_witness_line():
     assert 0 < ro["valu_butterflies"]["frac"] <= 1.0
     assert set(ro["phases_ms"]) == {"msm_core", "point_lists", "merge_forest", "coefficient_copy"}
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "compute_lhs_witness" in cb["sample"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "compute_lhs_witness" in cb["sample"]

@@ -32,9 +32,21 @@ def fctx(ctx, request):
 
 
 # ------------------------------------------------------------------ field / group KATs
-def test_device_montmul_reference_fr_chains(ctx):
-    """the device r-modulus multiplier regenerates all 192 constants of the reference's
-    src/precomputed_fft_data.rs (via digests in tests/golden/fr_mont_chains.json)"""
+@pytest.fixture(params=[0, 1], ids=["lazy29", "strict32"])
+def kctx(ctx, request):
+    """the known-answer entries run the arithmetic option `field` selects: 0 = the hot kernels' lazy radix-2^29 field
+    (Field29 / XYZZ29, the default), 1 = the strict 32-bit-limb field"""
+    ctx.set_option("field", request.param)
+    ctx.kat_field = request.param
+    yield ctx
+    ctx.set_option("field", 0)
+
+
+def test_device_montmul_reference_fr_chains(kctx):
+    """the device r-modulus multiplier -- Field29<Fr29Params>::mul of the hot kernels as well as the strict one --
+    regenerates all 192 constants of the reference's src/precomputed_fft_data.rs (via digests in
+    tests/golden/fr_mont_chains.json)"""
+    ctx = kctx
     chains = load_json("fr_mont_chains.json")
     def mm(a, b):
         return ctx.debug_montmul(api.GRUMPKIN, np.frombuffer(a, np.uint64), np.frombuffer(b, np.uint64)).tobytes()
@@ -44,7 +56,8 @@ def test_device_montmul_reference_fr_chains(ctx):
 
 
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
-def test_device_field_ops_random_and_edges(ctx, curve):
+def test_device_field_ops_random_and_edges(kctx, curve):
+    ctx = kctx
     p = curve.fp
     rng = pyref.SplitMix64(0xF1E1D + curve.cid)
     vals = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << 255) % p, (1 << 256) % p, (1 << 253)]
@@ -55,16 +68,20 @@ def test_device_field_ops_random_and_edges(ctx, curve):
     got = ctx.debug_montmul(curve.cid, a, b)
     for i, (x, y) in enumerate(zip(vals, reversed(vals))):
         assert int_of(got[i]) == x * y * rinv % p, ("mul", i)
-    for op, fn in ((0, lambda x, y: (x + y) % p), (1, lambda x, y: (x - y) % p), (2, lambda x, y: (-x) % p),
-                   (4, lambda x, y: x * x * rinv % p)):
+    ops = [(0, lambda x, y: (x + y) % p), (1, lambda x, y: (x - y) % p), (2, lambda x, y: (-x) % p), (4, lambda x, y: x * x * rinv % p)]
+    if ctx.kat_field == 0:   # the fused products of the lazy field (XYZZ29's X3 and Y3) and its cheap times-32
+        ops += [(5, lambda x, y: 2 * x * y * rinv % p), (6, lambda x, y: (x * x * rinv + y) % p), (7, lambda x, y: (x * y * rinv + y) % p),
+                (9, lambda x, y: x)]
+    for op, fn in ops:
         got = ctx.debug_fieldop(curve.cid, op, a, b)
         for i, (x, y) in enumerate(zip(vals, reversed(vals))):
             assert int_of(got[i]) == fn(x, y), (op, i)
     nz = a[1:40]
-    got = ctx.debug_fieldop(curve.cid, 3, nz, nz)   # Montgomery inverse: a^-1 * R^2 ... checked via product
+    got = ctx.debug_fieldop(curve.cid, 3, nz, nz)   # Montgomery inverse (field 0: inv_lazy)
     prod = ctx.debug_montmul(curve.cid, got, nz)
     R = (1 << 256) % p
     assert all(int_of(prod[i]) == R for i in range(len(nz)))
+    assert all(int_of(got[i]) == pow(vals[1 + i], -1, p) * R * R % p for i in range(len(nz)))
 
 
 def _xyzz_from_affine(curve, pt, z=1):
@@ -86,9 +103,10 @@ def _affine_from_xyzz(curve, rec):
 
 
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
-def test_device_point_ops_complete(ctx, curve):
-    """mixed add and full add incl. P+P, P+(-P), identity operands (the reference's own test shape
-    drives every bucket through the doubling branch)"""
+def test_device_point_ops_complete(kctx, curve):
+    """mixed add (both forms of the accumulate kernel: madd and madd_abi) and full add incl. P+P, P+(-P), identity
+    operands (the reference's own test shape drives every bucket through the doubling branch)"""
+    ctx = kctx
     rng = pyref.SplitMix64(0xADD + curve.cid)
     base = pyref.gen_points(curve, rng, 12)
     cases = []
@@ -99,9 +117,10 @@ def test_device_point_ops_complete(ctx, curve):
     zs = [1 + rng.next256() % (curve.fp - 1) for _ in cases]
     acc = np.array([_xyzz_from_affine(curve, a, z) for (a, _), z in zip(cases, zs)], np.uint64)
     q_aff = np.array([np.frombuffer(curve.affine_to_raw(b), np.uint64) for _, b in cases], np.uint64)
-    got = ctx.debug_pointop(curve.cid, 0, acc, q_aff)
-    for i, (a, b) in enumerate(cases):
-        assert _affine_from_xyzz(curve, got[i]) == curve.add(a, b), ("madd", i)
+    for op, name in ((0, "madd"), (2, "madd_abi")):
+        got = ctx.debug_pointop(curve.cid, op, acc, q_aff)
+        for i, (a, b) in enumerate(cases):
+            assert _affine_from_xyzz(curve, got[i]) == curve.add(a, b), (name, i)
     q_x = np.array([_xyzz_from_affine(curve, b, 1 + (z * 7) % (curve.fp - 1)) for (_, b), z in zip(cases, zs)], np.uint64)
     got = ctx.debug_pointop(curve.cid, 1, acc, q_x)
     for i, (a, b) in enumerate(cases):
@@ -1107,6 +1126,54 @@ def test_divisor_witness_half_size_transforms_equal_full_size(ctx, n):
         ctx.set_option("dw_wrap", 0)
     assert res[0][0].shape == res[1][0].shape and res[0][1].shape == res[1][1].shape
     assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
+
+
+@pytest.mark.parametrize("n", [3, 8, 9, 31, 64, 100, 1000, 2049, 6001, 20000])
+def test_divisor_witness_child_evaluation_reuse_equals_whole_transforms(ctx, n):
+    """option dw_reuse: from the second merge level on a node transforms its children onto the ODD half of its domain only
+    and reads the even half from the evaluations the level below left (a passed-through child -- the ragged right edge of
+    a tree -- through a side transform): the same witness, coefficient for coefficient, as with whole transforms; lists with
+    an identity and a repeated point; the counter says the reuse path really ran"""
+    g = pyref.GRUMPKIN
+    q = cref.gen_points(g.cid, 1750 + n, 1)[0]
+    rows = ctx.gen_walk(g.cid, q, n).download(np.uint64).reshape(-1, 8).copy()
+    if n >= 9:
+        rows[2] = 0; rows[n - 3] = rows[1]
+    res = []
+    try:
+        for mode in (0, 2):
+            ctx.set_option("dw_reuse", mode)
+            a, b, outp = ctx.divisor_witness(api.GRUMPKIN, rows, False, True)
+            res.append((a.copy(), b.copy(), outp.copy(), ctx.divisor_last_reuse_levels()))
+    finally:
+        ctx.set_option("dw_reuse", 0)
+    assert res[0][0].shape == res[1][0].shape and res[0][1].shape == res[1][1].shape
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
+    assert res[1][3] == 0
+    if n >= 64:
+        assert res[0][3] >= 2, res[0][3]
+
+
+def test_divisor_witness_batch_reuse_with_ragged_trees(ctx):
+    """a forest of trees of different shapes (every kind of ragged right edge at once) with and without reuse"""
+    g = pyref.GRUMPKIN
+    counts = [1, 2, 3, 5, 6, 7, 12, 13, 33, 64, 65, 127, 200, 513]
+    q = cref.gen_points(g.cid, 1790, 1)[0]
+    rows = ctx.gen_walk(g.cid, q, sum(counts)).download(np.uint64).reshape(-1, 8).copy()
+    res = []
+    try:
+        for mode in (0, 2):
+            ctx.set_option("dw_reuse", mode)
+            lists = []; o = 0
+            for c in counts:
+                lists.append(rows[o:o + c]); o += c
+            res.append(ctx.divisor_witness_batch(api.GRUMPKIN, lists, False, True))
+    finally:
+        ctx.set_option("dw_reuse", 0)
+    assert len(res[0]) == len(res[1]) == len(counts)
+    for t in range(len(counts)):
+        for part in range(3):
+            assert np.array_equal(np.asarray(res[0][t][part]), np.asarray(res[1][t][part])), (t, part)
 
 
 @pytest.mark.parametrize("n", [2, 5, 16, 17, 300, 1024, 5000])

@@ -60,6 +60,26 @@ ec, ecs = cref.lhs_msm(0, sch, cref.aff_to_jac(0, pts), 16)
 c, cs = ctx.lhs_msm_sharded_device(0, dsh.ptr, dp.ptr, n, 16)
 assert cref.jac_to_canonical(0, c) == cref.jac_to_canonical(0, ec)
 assert all(cref.jac_to_canonical(0, cs[i]) == cref.jac_to_canonical(0, ecs[i]) for i in range(cs.shape[0]))
+# (1b) failures stay collective-safe: a non-canonical scalar is reported from the gathered status slots, and a rank whose
+# own pipeline cannot start (here: rejected input points) still enters the exchange with a stand-in buffer carrying its status
+from halo2_liam_eagen_msm_amd import api
+bad = sc.copy(); bad[1234] = 0xff
+dbad = ctx.to_device(bad)
+try:
+    ctx.msm_sharded_device(0, dbad.ptr, dp.ptr, n); raise SystemExit("expected ScalarOutOfRange")
+except api.ScalarOutOfRange as e:
+    assert e.index == 1234, e.index
+offcurve = pts.copy(); offcurve[77, 0] ^= 1
+doff = ctx.to_device(offcurve)
+ctx.set_option("validate_points", 1)
+for call in (lambda: ctx.msm_sharded_device(0, ds.ptr, doff.ptr, n), lambda: ctx.lhs_msm_sharded_device(0, dsh.ptr, doff.ptr, n, 16)):
+    try:
+        call(); raise SystemExit("expected a bad-argument status")
+    except api.LemsmError as e:
+        assert e.status == 6, e.status          # LEMSM_ERR_BAD_ARG
+ctx.set_option("validate_points", 0)
+assert ctx.comm_info() == (1, 0)          # the communicator survived: the failing rank took part in the exchange
+assert cref.jac_to_canonical(0, ctx.msm_sharded_device(0, ds.ptr, dp.ptr, n)) == exp
 ctx.comm_destroy(); assert ctx.comm_info() == (0, 0)
 ctx.close()
 # (2) one process, N GPUs form (N = 1 here): contexts + communicators + threads inside the library

@@ -2,11 +2,15 @@
 Horner tails (lemsm_msm_combine / lemsm_lhs_combine) fed with oracle-built window records, and
 canonicalisation.  No device entry point is called."""
 import ctypes
+import os
+import sys
 
 import numpy as np
 import pytest
 
 import hostref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from helpers import CURVES, canon
 from halo2_liam_eagen_msm_amd import _lib, api
 from oracle import cref, pyref
@@ -170,3 +174,31 @@ def test_to_curve_x_y_from_x_slope(curve):
     assert flag and _unmont(y, p) in (gy, p - gy)
     with pytest.raises(ZeroDivisionError):
         api.slope(np.concatenate([_mont(gx, p), np.zeros(4, np.uint64)]), curve.cid)
+
+
+# ------------------------------------------------------------------ sanitizer runs (CPU only)
+def test_host_tail_under_asan_ubsan(tmp_path):
+    """the product's host tail (csrc/hosttail.hpp, hostmath.hpp, hostpool.hpp: record conversion, window / final Horner,
+    pyramid task tables, merge queue layout, worker pool) compiled alone with -fsanitize=address,undefined and driven on
+    synthetic data, the task tables simulated on integers (tests/host_tail_check.cpp)"""
+    import subprocess
+    exe = tmp_path / "host_tail_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           "-pthread", "-o", str(exe), os.path.join(ROOT, "tests", "host_tail_check.cpp")])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "host tail ok" in out.stdout, out.stdout + out.stderr
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr
+
+
+def test_oracle_c_under_asan_ubsan():
+    """the C oracle (test infrastructure) rebuilt with -fsanitize=address,undefined (`make -C oracle asan`) and the golden-vector
+    tests of tests/test_oracle_golden.py run against that build in a child interpreter with libasan preloaded"""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1",
+               LEMSM_ORACLE_LIB=os.path.join(ROOT, "oracle", "_build", "liblemsm_oracle_asan.so"))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_golden.py"), "-x", "-q", "-p", "no:cacheprovider",
+                          "-k", "not asan"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]

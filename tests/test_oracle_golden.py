@@ -10,6 +10,7 @@
 The reference holds no MSM known-answer vectors: MSM byte parity is "parity unpinned" by the
 reference and is defined as equality of group elements in canonical affine form.
 """
+import json
 import math
 import os
 import random
@@ -19,6 +20,8 @@ import pytest
 
 from helpers import CURVES, canon, golden_points_raw, golden_scalars, load_json, regenerate_chain_digests
 from oracle import cref, pyref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REF_FILE = "/root/reference/src/precomputed_fft_data.rs"
 
@@ -191,3 +194,66 @@ def test_walk_relation():
     sc = cref.gen_scalars(0, 11, 300)
     dot = cref.walk_dot(0, sc)
     assert canon(c, cref.best_multiexp(0, sc, w, 2)) == c.canonical(c.mul(dot, qa))
+
+
+# ------------------------------------------------------------------ compiled witness restatement vs the Python one
+def _omega0():
+    chains = json.load(open(os.path.join(ROOT, "tests", "golden", "fr_mont_chains.json")))
+    head = bytes.fromhex(chains["omega_pow"]["head"])
+    return np.frombuffer(head, np.uint64).copy(), int.from_bytes(head, "little")
+
+
+def _jac_ints(pts_jac, p):
+    ri = pow(1 << 256, -1, p)
+    out = []
+    for row in np.ascontiguousarray(pts_jac, np.uint64).reshape(-1, 12):
+        b = row.tobytes()
+        out.append(tuple(int.from_bytes(b[32 * i:32 * i + 32], "little") * ri % p for i in range(3)))
+    return out
+
+
+@pytest.mark.parametrize("n,threads", [(1, 1), (2, 1), (3, 2), (7, 1), (31, 3), (64, 2), (150, 4), (301, 3)])
+def test_c_divisor_witness_equals_python_restatement(n, threads):
+    """oracle/c/witness_oracle.inc (the timed CPU baseline of the witness path: schoolbook below 32 coefficients, radix-2 FFT
+    with the pinned omega above, threads over the pairs of a level) against oracle/divisor.py, coefficient for coefficient
+    after normalisation, lengths exactly -- n >= 64 takes the products through the FFT"""
+    from oracle import divisor as dv
+    omega_raw, head = _omega0()
+    c = pyref.GRUMPKIN
+    O = dv.DivisorOracle(c, dv.FrFft(c.fp, head * pow(1 << 256, -1, c.fp) % c.fp))
+    pts = cref.aff_to_jac(1, cref.gen_points(1, 4000 + n, n))
+    # close the list with minus the sum so that the witness exists (:478)
+    acc = np.zeros(12, np.uint64)
+    for row in pts:
+        acc = cref.jac_add(1, acc, row)
+    neg = acc.copy()
+    yb = int.from_bytes(neg[4:8].tobytes(), "little")
+    if int.from_bytes(neg[8:12].tobytes(), "little"):
+        neg[4:8] = np.frombuffer(((c.fp - yb) % c.fp).to_bytes(32, "little"), np.uint64)
+    full = np.vstack([pts, neg.reshape(1, 12)])
+    st, a, b = cref.divisor_witness(full, omega_raw, threads)
+    assert st == 0
+    want = O.compute_divisor_witness(_jac_ints(full, c.fp))
+    assert (len(a), len(b)) == (len(want[0]), len(want[1]))
+    assert O.normalise((a, b)) == O.normalise(want)
+    # without the closing point the reference panics (:478)
+    st, _, _ = cref.divisor_witness(pts, omega_raw, threads)
+    assert st == 1
+
+
+@pytest.mark.parametrize("n,base,threads", [(5, 5, 1), (40, 16, 4), (130, 3, 3)])
+def test_c_lhs_witness_equals_python_restatement(n, base, threads):
+    from oracle import divisor as dv
+    omega_raw, head = _omega0()
+    c = pyref.GRUMPKIN
+    O = dv.DivisorOracle(c, dv.FrFft(c.fp, head * pow(1 << 256, -1, c.fp) % c.fp))
+    pts = cref.aff_to_jac(1, cref.gen_points(1, 4100 + n, n))
+    sc = cref.gen_scalars(1, 4200 + n, n, half=True)
+    st, carry, fs = cref.lhs_witness(sc, pts, base, omega_raw, threads)
+    assert st == 0
+    ecarry, efs = dv.compute_lhs_witness(O, [int.from_bytes(s.tobytes(), "little") for s in sc], _jac_ints(pts, c.fp), base)
+    assert cref.jac_to_canonical(1, carry) == c.canonical(O.to_affine(ecarry))
+    assert len(fs) == len(efs)
+    for f, (got, want) in enumerate(zip(fs, efs)):
+        assert (len(got[0]), len(got[1])) == (len(want[0]), len(want[1])), f
+        assert O.normalise(got) == O.normalise(want), f
