@@ -608,10 +608,32 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
   fe ninv; ld(ninv, consts + 8);
   fe c0, c1, d0, lX, lZZ, rX, rZZ;
   const bool divide = pl.mode == MODE_DIVIDE;
+  // reuse mode, even half of the domain: values kept from the level below carry its 1/(N/2) (the scale of its inverse
+  // transform rode on its numerators); it is undone through the scale of this level's numerators: (N/2)^kept
+  const bool even_half = odd != nullptr && !extra && i < (N >> 1);
+  const u32 kept = even_half ? (pl.evk[0] == 0 ? 1u : 0u) + (pl.evk[1] == 0 ? 1u : 0u) : 0u;
+  fe scale = ninv;                                                        // 1/N of the inverse transform (x (N/2)^kept)
+  // The scaled line coefficients are the same for every slot of a node's half: where a whole block lies inside one
+  // (N >= 512), three lanes compute them once for the block instead of every lane for itself (6 of ~18 products per slot)
+  __shared__ u32 shc[3][8];
+  const bool uni = logN >= 9 && ((u64)blockIdx.x + 1) * 256 <= per;
   if (divide) {
-    ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0); ld(lX, pl.lX); ld(lZZ, pl.lZZ); ld(rX, pl.rX); ld(rZZ, pl.rZZ);
-    F::mul(c0, c0, ninv); F::mul(c1, c1, ninv); F::mul(d0, d0, ninv);   // the numerator is linear in the line: 1/N of the inverse transform rides on it
-  }
+    ld(lX, pl.lX); ld(lZZ, pl.lZZ); ld(rX, pl.rX); ld(rZZ, pl.rZZ);
+    if (uni) {
+      if (threadIdx.x < 3) {
+        fe c; ld(c, threadIdx.x == 0 ? pl.c0 : (threadIdx.x == 1 ? pl.c1 : pl.d0));
+        F::mul(c, c, ninv);
+        if (kept) { fe sc; ld(sc, consts + (kept == 2 ? 48 : 40)); F::mul(c, c, sc); }
+        st(shc[threadIdx.x], c);
+      }
+      __syncthreads();
+      ld(c0, shc[0]); ld(c1, shc[1]); ld(d0, shc[2]);
+    } else {
+      ld(c0, pl.c0); ld(c1, pl.c1); ld(d0, pl.d0);
+      if (kept) { fe sc; ld(sc, consts + (kept == 2 ? 48 : 40)); F::mul(scale, scale, sc); }
+      F::mul(c0, c0, scale); F::mul(c1, c1, scale); F::mul(d0, d0, scale);   // the numerator is linear in the line: the scale rides on it
+    }
+  } else if (kept) { fe sc; ld(sc, consts + (kept == 2 ? 48 : 40)); F::mul(scale, scale, sc); }
   fe x, sv, La, Lb, Ra, Rb, A, Bv, den;
   if (extra) { F::set_zero(x); ld(sv, consts); }                         // x = 0: 0^3 + b
   else { ld(x, XS + (size_t)i * 16); ld(sv, XS + (size_t)i * 16 + 8); }  // x_i, x_i^3 + b (= y^2)
@@ -623,23 +645,17 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
       const u32* o = odd + ((((size_t)k << logNh) + (i - Nh)) * 8);
       ld(La, o); ld(Lb, o + perh * 8); ld(Ra, o + 2 * perh * 8); ld(Rb, o + 3 * perh * 8);
     } else {
-      // even half: the children's own domain.  Values kept from the level below carry its 1/(N/2) (the scale of its inverse
-      // transform rode on the numerators): undone here through the scale of this level's numerators
-      u32 kept = 0;
+      // even half: the children's own domain -- the level below's transform buffer, or the side buffer of a passed-through child
 #pragma unroll
       for (int side = 0; side < 2; side++) {
         const u32* pa; const u32* pb;
-        if (pl.evk[side] == 0) { const u32 c = pl.child0 + side; pa = evprev + ((((size_t)c << logNh) + i) * 8); pb = pa + ((size_t)nn_prev << logNh) * 8; kept++; }
+        if (pl.evk[side] == 0) { const u32 c = pl.child0 + side; pa = evprev + ((((size_t)c << logNh) + i) * 8); pb = pa + ((size_t)nn_prev << logNh) * 8; }
         else { pa = evexc + (((size_t)(2 * pl.tree) << logNh) + i) * 8; pb = pa + ((size_t)1 << logNh) * 8; }
         if (side == 0) { ld(La, pa); ld(Lb, pb); } else { ld(Ra, pa); ld(Rb, pb); }
       }
-      if (kept) {
-        fe sc; ld(sc, consts + (kept == 2 ? 48 : 40));        // (N/2)^2 or N/2
-        if (divide) { F::mul(c0, c0, sc); F::mul(c1, c1, sc); F::mul(d0, d0, sc); } else F::mul(ninv, ninv, sc);
-      }
     }
   }
-  pw_numerators(A, Bv, den, divide, x, sv, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, ninv);
+  pw_numerators(A, Bv, den, divide, x, sv, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, scale);
   if (divide && F::is_zero(den)) { atomicOr(&stats[extra ? STAT_ZERO0 : STAT_ZERODEN], 1u); F::set_one(den); }
   if (extra) {
     st(c0out + ((size_t)0 * nnodes + k) * 8, A); st(c0out + ((size_t)1 * nnodes + k) * 8, Bv);
