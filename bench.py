@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--logn", type=int, default=None)
     ap.add_argument("--curve", choices=["bn254_g1", "grumpkin"], default="bn254_g1")
     ap.add_argument("--base", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=1,
+                    help="msm, one GPU: a step is a BATCH of this many MSMs over the same resident points through lemsm_msm_batch_device (calls pipelined "
+                         "over two lanes inside the library); 1 = the headline single call.  A separately labelled workload, never the default")
     ap.add_argument("--cpu-sample-log", type=int, default=None, help="log2 of the cpu_baseline sample size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["rccl-abi", "torch"], default="rccl-abi",
@@ -158,6 +161,8 @@ def main():
 
     def step():
         if args.workload == "msm":
+            if world == 1 and args.batch > 1:
+                return ctx.msm_batch_device(cid, [d_scalars.ptr] * args.batch, d_points.ptr, n)[-1]
             if world == 1:
                 return ctx.msm_device(cid, d_scalars.ptr, d_points.ptr, n)
             if args.sharding == "points":
@@ -199,7 +204,8 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = n * args.steps / elapsed
+        batch = args.batch if (args.workload == "msm" and world == 1) else 1
+        value = n * batch * args.steps / elapsed
         # dominant kernel: k_accum1 (one launch per window group; one group at these sizes)
         launches = max(launches, 1)
         accum_ms = acc_ms / launches
@@ -256,6 +262,11 @@ def main():
         # bit_exact is derived from checks that ran in THIS process (each raises on a mismatch); null when none did
         if args.option:
             out["config"]["options"] = args.option
+        if batch > 1:
+            out["config"]["workload"] += ", BATCH of %d calls over the same resident points per step (lemsm_msm_batch_device: two lanes, call k's tail and host fold under call k+1)" % batch
+            out["config"]["batch"] = batch
+            out["config"]["baseline_config"] = "none (batched variant of configs[1] / configs[2]; the headline line is the single call)"
+            out["roofline"]["note"] += "; batch run: kernel_ms / launches are those of the first lane's calls only"
         out["config"]["merge_queues"] = {"short_3to8": merge_counts[0], "medium_9to32": merge_counts[1], "long_slices": merge_counts[2], "multi_slice_buckets": merge_counts[3]}
         out["config"]["bit_exact"] = True if checks else None
         out["config"]["bit_exact_checks"] = checks

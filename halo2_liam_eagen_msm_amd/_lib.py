@@ -38,7 +38,7 @@ GRUMPKIN = 1
 SYMBOLS = [
     "lemsm_create", "lemsm_destroy", "lemsm_strerror", "lemsm_last_error", "lemsm_last_bad_index", "lemsm_last_truncated_count", "lemsm_set_option",
     "lemsm_last_timing", "lemsm_last_accum_clock_mhz", "lemsm_debug_last_merge_counts", "lemsm_debug_divisor_last_reuse_levels",
-    "lemsm_msm", "lemsm_msm_bn254_g1", "lemsm_msm_grumpkin", "lemsm_msm_device",
+    "lemsm_msm", "lemsm_msm_bn254_g1", "lemsm_msm_grumpkin", "lemsm_msm_device", "lemsm_msm_batch_device",
     "lemsm_msm_plan", "lemsm_msm_partial_device", "lemsm_msm_combine",
     "lemsm_num_digits", "lemsm_negbase_decompose_batch",
     "lemsm_lhs_msm", "lemsm_lhs_msm_grumpkin", "lemsm_lhs_msm_bn254_g1", "lemsm_lhs_msm_device",
@@ -103,6 +103,7 @@ def load() -> ctypes.CDLL:
         "lemsm_msm_bn254_g1": (i, [vp, u8p, u64p, sz, u64p]),
         "lemsm_msm_grumpkin": (i, [vp, u8p, u64p, sz, u64p]),
         "lemsm_msm_device": (i, [vp, i, vp, vp, sz, u64p]),
+        "lemsm_msm_batch_device": (i, [vp, i, ctypes.POINTER(ctypes.c_void_p), sz, vp, sz, u64p]),
         "lemsm_msm_plan": (i, [vp, i, sz, u32p, szp]),
         "lemsm_msm_partial_device": (i, [vp, i, vp, vp, sz, ctypes.c_uint32, ctypes.c_uint32, u8p]),
         "lemsm_msm_combine": (i, [vp, i, sz, u8p, u64p]),

@@ -249,6 +249,15 @@ class Context:
         self._check(self.lib.lemsm_msm_device(self.h, _curve_id(curve), d_scalars, d_points, n, _ptr(out)))
         return out
 
+    def msm_batch_device(self, curve, d_scalars_list, d_points: int, n: int) -> np.ndarray:
+        """len(d_scalars_list) MSMs over the same resident points, pipelined inside the library (lemsm_msm_batch_device);
+        returns (K, 12) Jacobian results"""
+        K = len(d_scalars_list)
+        out = np.zeros((max(K, 1), 12), np.uint64)
+        ptrs = (ctypes.c_void_p * max(K, 1))(*[int(p) for p in d_scalars_list])
+        self._check(self.lib.lemsm_msm_batch_device(self.h, _curve_id(curve), ptrs, K, d_points, n, _ptr(out)))
+        return out[:K]
+
     def msm_plan(self, curve, n: int) -> Tuple[int, int]:
         w = ctypes.c_uint32()
         b = ctypes.c_size_t()

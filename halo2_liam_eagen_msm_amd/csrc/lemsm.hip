@@ -104,6 +104,7 @@ struct lemsm_ctx {
   ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;   // lemsm_comm_init
   int plan_world = 1;   // ranks sharing the current call's windows: > 1 pins 16-bit windows (16 split evenly over 2/4/8 ranks, 15 do not)
   u32* h_small = nullptr;                        // 256 pinned bytes: error words of the negabase digit pass
+  lemsm_ctx* peer = nullptr;                      // second lane of lemsm_msm_batch_device: own queues, workspace and pinned buffer on the same device
   void* h_pin = nullptr; size_t h_pin_cap = 0;   // pinned staging for the read-back of one call's records (one async copy, no pageable bounce)
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
@@ -965,6 +966,46 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
   return rc;
 }
 
+// K MSMs over the same points, pipelined over two lanes (the context and its peer: own queues, workspace, pinned buffer):
+// while the GPU works on call k, the host folds the records of call k - 1, and call k - 1's latency-bound tail (merge +
+// pyramid: a few dozen dependent launches that occupy a fraction of the chip) runs beside call k's digit / sort passes
+// and fills the wave slots its accumulation leaves.  Matches how a prover uses best_multiexp: many calls, one SRS.
+template <class P64, class G>
+int msm_batch_t(lemsm_ctx* ctx, int curve, const void* const* d_scalars, const void* d_points, size_t n, size_t K, u64* outs) {
+  lemsm_ctx* lane[2] = {ctx, ctx->peer};
+  MsmPlan mp = make_msm_plan(ctx, curve, n);
+  WinRun wr[2];
+  auto enqueue = [&](size_t k) -> int {
+    lemsm_ctx* c = lane[k & 1];
+    const void* sc = d_scalars[k];
+    auto make_src = [&](size_t s0, u32) {
+      PipProvider s; s.scalars = (const uint4*)((const char*)sc + s0 * 32);
+      memcpy(s.kadd.k, mp.kadd, 32); memcpy(s.kadd.order, order_of(curve), 32); return s;
+    };
+    return run_windows_enqueue<P64, G>(c, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, 0, mp.W, 0, d_points, mp.W, wr[k & 1]);
+  };
+  auto finish = [&](size_t k) -> int {
+    lemsm_ctx* c = lane[k & 1];
+    std::vector<char> raw;
+    int rc = run_windows_finish(c, wr[k & 1], wr[k & 1].d_out, wr[k & 1].send_bytes(), raw);
+    if (rc) { ctx->last_error = c->last_error; ctx->bad_index = c->bad_index; return rc; }
+    std::vector<host::pt> sums;
+    sum_slab_records<P64, G>(ctx, raw.data(), wr[k & 1].out_slab, wr[k & 1].nslabs, mp.W, mp.L, sums, true);
+    msm_combine_t<P64>(mp, sums.data(), outs + 12 * k);
+    return LEMSM_OK;
+  };
+  int rc = LEMSM_OK; size_t enq = 0;
+  for (size_t k = 0; k < K && !rc; k++) {
+    rc = enqueue(k);
+    if (rc) { if (lane[k & 1] != ctx) ctx->last_error = lane[k & 1]->last_error; break; }
+    enq = k + 1;
+    if (k > 0) rc = finish(k - 1);
+  }
+  if (!rc && enq == K && K) rc = finish(K - 1);
+  if (rc) for (lemsm_ctx* c : lane) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }   // nothing of this call may still run when it returns
+  return rc;
+}
+
 int check_curve(lemsm_ctx* ctx, int curve) {
   if (curve != LEMSM_BN254_G1 && curve != LEMSM_GRUMPKIN) return fail(ctx, LEMSM_ERR_BAD_CURVE, "unknown curve id");
   return LEMSM_OK;
@@ -1500,6 +1541,7 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   if (ctx->stream_tail) { (void)hipStreamSynchronize(ctx->stream_tail); (void)hipStreamDestroy(ctx->stream_tail); }
   for (hipEvent_t e : ctx->evpool) (void)hipEventDestroy(e);
   if (ctx->comm) { (void)Rccl::get().CommDestroy(ctx->comm); ctx->comm = nullptr; }
+  if (ctx->peer) { lemsm_destroy(ctx->peer); ctx->peer = nullptr; }
   ctx->pool.reset();
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->h_small) (void)hipHostFree(ctx->h_small);
@@ -1616,6 +1658,31 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   ctx->host_us[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
   if (getenv("LEMSM_DEBUG_STAMPS")) fprintf(stderr, "[lemsm] host tail (us): device wait %.1f, records + window sums %.1f, (unused) %.1f, Horner %.1f\n", ctx->host_us[0], ctx->host_us[1], ctx->host_us[2], ctx->host_us[3]);
   return LEMSM_OK;
+}
+
+int lemsm_msm_batch_device(lemsm_ctx* ctx, int curve, const void* const* d_scalars, size_t batch, const void* d_points, size_t n, uint64_t* outs) {
+  if (!ctx || (batch && (!d_scalars || !outs))) return LEMSM_ERR_BAD_ARG;
+  int rc = check_curve(ctx, curve); if (rc) return rc;
+  if (batch == 0) return LEMSM_OK;
+  if (n == 0) { memset(outs, 0, batch * 96); return LEMSM_OK; }
+  for (size_t k = 0; k < batch; k++) if (!d_scalars[k]) return LEMSM_ERR_BAD_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  rc = validate_points(ctx, curve, d_points, n); if (rc) return rc;
+  if (ctx->opt_field == 1 || ctx->opt_groups > 1 || batch == 1) {       // A/B arithmetic, pipelined window groups, or nothing to overlap: one call after the other
+    for (size_t k = 0; k < batch; k++) { rc = lemsm_msm_device(ctx, curve, d_scalars[k], d_points, n, outs + 12 * k); if (rc) return rc; }
+    return LEMSM_OK;
+  }
+  if (!ctx->peer) { rc = lemsm_create(ctx->device, &ctx->peer); if (rc) return fail(ctx, rc, "lemsm_msm_batch_device: second lane could not be created"); }
+  {   // the peer plans exactly like the context
+    lemsm_ctx* p = ctx->peer;
+    p->opt_window_bits = ctx->opt_window_bits; p->opt_chunk = ctx->opt_chunk; p->opt_tile = ctx->opt_tile; p->opt_field = ctx->opt_field;
+    p->opt_accum_waves = ctx->opt_accum_waves; p->opt_groups = ctx->opt_groups; p->opt_slab_bits = ctx->opt_slab_bits; p->opt_abi_points = ctx->opt_abi_points;
+    p->opt_stage2x = ctx->opt_stage2x; p->opt_xcd_windows = ctx->opt_xcd_windows; p->opt_entry_ring = ctx->opt_entry_ring; p->opt_pyr_fuse = ctx->opt_pyr_fuse;
+    p->opt_ws_canary = ctx->opt_ws_canary; p->opt_binsort = ctx->opt_binsort; p->opt_merge_slice = ctx->opt_merge_slice; p->opt_merge_wave_th = ctx->opt_merge_wave_th;
+    p->opt_pyr_first2 = ctx->opt_pyr_first2; p->opt_host_threads = ctx->opt_host_threads; p->plan_world = ctx->plan_world;
+  }
+  if (curve == LEMSM_BN254_G1) return msm_batch_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, batch, outs);
+  return msm_batch_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, batch, outs);
 }
 
 int lemsm_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* points, size_t n, uint64_t out[12]) {

@@ -131,6 +131,13 @@ int lemsm_debug_last_merge_counts(const lemsm_ctx* ctx, uint64_t out[4]);
 /* sum_i scalars[i] * points[i]; host buffers. */
 int lemsm_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* points_affine,
               size_t n, uint64_t out_jacobian[12]);
+/* `batch` MSMs over the same points: sum_i scalars_k[i] * points[i] for k < batch; d_scalars[k]: device pointer to n x 32 B,
+   outs: batch x 12 limbs.  The calls are pipelined over two lanes of queues and workspaces: the host tail of call k - 1 and
+   its latency-bound bucket-reduction tail overlap call k's passes (a prover calls best_multiexp many times over one SRS:
+   /root/reference/src/argument_witness_calc.rs:144, src/regular_functions_utils.rs:655-726).  Results equal `batch`
+   separate lemsm_msm_device calls; the first failing call's status is returned. */
+int lemsm_msm_batch_device(lemsm_ctx* ctx, int curve, const void* const* d_scalars, size_t batch, const void* d_points_affine,
+                           size_t n, uint64_t* outs);
 int lemsm_msm_bn254_g1(lemsm_ctx* ctx, const uint8_t* scalars, const uint64_t* points_affine,
                        size_t n, uint64_t out_jacobian[12]);
 int lemsm_msm_grumpkin(lemsm_ctx* ctx, const uint8_t* scalars, const uint64_t* points_affine,

@@ -299,6 +299,34 @@ def test_lhs_edge_record_merge_long_buckets(fctx):
     assert counts[2] > 0 and counts[3] > 0, counts
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm_batch_equals_separate_calls(ctx, curve):
+    """lemsm_msm_batch_device: K MSMs over one set of points, pipelined over two lanes inside the library -- the results of
+    K separate calls, in order; a non-canonical scalar in one call fails the batch with that call's status"""
+    n = 7000
+    pts = cref.gen_points(curve.cid, 950, n)
+    dp = ctx.to_device(pts)
+    scs = [cref.gen_scalars(curve.cid, 960 + k, n) for k in range(5)]
+    dss = [ctx.to_device(s) for s in scs]
+    got = ctx.msm_batch_device(curve.cid, [d.ptr for d in dss], dp.ptr, n)
+    assert got.shape == (5, 12)
+    for k in range(5):
+        assert canon(curve, got[k]) == canon(curve, cref.best_multiexp(curve.cid, scs[k], pts, 8)), k
+        assert canon(curve, got[k]) == canon(curve, ctx.msm_device(curve.cid, dss[k].ptr, dp.ptr, n)), k
+    assert ctx.msm_batch_device(curve.cid, [], dp.ptr, n).shape[0] == 0
+    one = ctx.msm_batch_device(curve.cid, [dss[2].ptr], dp.ptr, n)
+    assert canon(curve, one[0]) == canon(curve, got[2])
+    bad = scs[3].copy(); bad[4321] = 0xff
+    dbad = ctx.to_device(bad)
+    with pytest.raises(api.ScalarOutOfRange) as e:
+        ctx.msm_batch_device(curve.cid, [dss[0].ptr, dss[1].ptr, dbad.ptr, dss[4].ptr], dp.ptr, n)
+    assert e.value.index == 4321
+    # the context (both lanes) is usable afterwards
+    again = ctx.msm_batch_device(curve.cid, [d.ptr for d in dss[:3]], dp.ptr, n)
+    for k in range(3):
+        assert canon(curve, again[k]) == canon(curve, got[k])
+
+
 def test_msm_all_zero_scalars_and_all_identity_points(fctx):
     ctx = fctx
     curve = pyref.GRUMPKIN
