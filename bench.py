@@ -276,7 +276,8 @@ def main():
         dist.destroy_process_group()
 
 
-BUTTERFLY_PEAK = 115e9   # ~1200 issue cycles per wave-butterfly (strict 8x32-bit Montgomery product + add + sub) on 1024 SIMDs at 2.1 GHz
+BUTTERFLY_PEAK = 112.7e9   # MEASURED register-only rate of the strict-field butterfly on the whole chip, 3 waves per SIMD (tools/ubench/butterfly_rates.hip,
+                           # profiles/r03/d_butterfly_rates_strict_vs_lazy.txt); the r02 model (~1200 issue cycles per wave-butterfly at 2.1 GHz) said 115e9
 
 
 def bench_lhs_witness(args, ctx, n, logn, world, rank, dist, torch, red_dev):
@@ -334,12 +335,14 @@ def bench_lhs_witness(args, ctx, n, logn, world, rank, dist, torch, red_dev):
     achieved = ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
     coeffs = int(index[:, 1].sum() + index[:, 3].sum())
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel": "k_ntt_tile (forward and inverse transforms of the merge forest, all levels of one call)",
+                "traffic": witness_traffic(logn, world, args), "traffic_source": "committed rocprofv3 PMC passes (profiles/traffic_witness.json; only the sizes measured there, else null), not measured in this run",
+                "kernel": "k_ntt_tile (forward and inverse transforms of the merge forest, all levels of one call)",
+                "reuse_levels": ctx.divisor_last_reuse_levels(),
                 "kernel_ms": round(ntt_ms / args.steps, 3), "algorithmic_bytes_per_step": ntt_bytes // args.steps,
                 "note": "LDS-tiled transforms are bound by the field multiplication, not by HBM (DESIGN.md section 6): butterflies/s against the VALU ceiling below",
                 "valu_butterflies": {"achieved_G_s": round(ntt_bf / (ntt_ms * 1e-3) / 1e9, 1) if ntt_ms > 0 else 0.0, "peak_G_s": BUTTERFLY_PEAK / 1e9,
                                      "frac": round(ntt_bf / (ntt_ms * 1e-3) / BUTTERFLY_PEAK, 4) if ntt_ms > 0 else 0.0,
-                                     "model": "model-derived peak: ~1200 issue cycles per wave-butterfly x 1024 SIMDs at 2.1 GHz"},
+                                     "model": "measured peak: register-only butterfly loop of the same field on the whole chip (profiles/r03/d_butterfly_rates_strict_vs_lazy.txt)"},
                 "phases_ms": {k: round(float(v) / args.steps, 2) for k, v in zip(("msm_core", "point_lists", "merge_forest", "coefficient_copy"), phases)}}
     checks = verify_lhs_witness(ctx, cid, scalars, q, d_points, n, args.base, carry, index, out, f_range)
     res = {"metric": "Grumpkin compute_lhs_witness scalar-point-pairs/s (carry + %d divisor witnesses)" % d, "value": round(n * args.steps / elapsed, 1), "unit": "pairs/s",
@@ -453,6 +456,16 @@ def cpu_baseline_lhs_witness(ctx, cid, scalars, d_points, args):
             raise SystemExit("GPU divisor witness %d differs from the CPU oracle on the sample: parity broken" % f)
     return {"value": round(m / dt, 1), "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": "first 2^%d pairs of the same inputs, compute_lhs_witness restatement in C (oracle/c/witness_oracle.inc: the reference's products -- schoolbook below 32 coefficients, radix-2 FFT above -- with the %d merge trees spread over %d threads), %.2f s, GPU result on the sample: carry and all %d functions equal" % (slog, len(efns), threads, dt, len(efns))}
+
+
+def witness_traffic(logn, world, args):
+    """HBM bytes of the transform launches of one compute_lhs_witness call from the committed PMC passes, or None"""
+    if world != 1 or args.option or args.base != 16:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic_witness.json")))["lhs_witness/grumpkin/2^%d/x1/base16" % logn]["bytes_per_call"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def pmc_traffic(workload, curve, logn, world):
