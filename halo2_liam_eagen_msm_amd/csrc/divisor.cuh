@@ -546,6 +546,12 @@ __global__ __launch_bounds__(256) void k_domain(u32 logN, const u32* __restrict_
   eval_point(x, W, log_half_max, logN, i); F::mul(x, x, cg);            // the coset keeps x_i - c != 0
   F::sqr(t, x); F::mul(t, t, x); F::add(s, t, cb);
   st(XS + (size_t)i * 16, x); st(XS + (size_t)i * 16 + 8, s);
+  // the same two in the lazy field's own domain (x 2^261 = 32 x 2^256), canonical: operands of pw_numerators29
+  fe x5 = x, s5 = s;
+#pragma unroll
+  for (int d = 0; d < 5; d++) { F::add(x5, x5, x5); F::add(s5, s5, s5); }
+  u32* XS32 = XS + ((size_t)16 << logN);            // a second table behind the first (the strict path's table keeps its 64-byte stride)
+  st(XS32 + (size_t)i * 16, x5); st(XS32 + (size_t)i * 16 + 8, s5);
 }
 
 // The pointwise step of a level, in two kernels: k_pw_num (numerators and denominators, a thread per slot) and k_pw_inv
@@ -584,10 +590,63 @@ __device__ __forceinline__ void pw_numerators(fe& A, fe& Bv, fe& den, bool divid
   }
 }
 
-// pass A: one thread per slot (and one per node for the extra slot x = 0 of wrap mode, gid >= nnodes * N): numerators
+// The same in the lazy 9 x 29-bit field (field29.cuh): a product is ~200 instructions there against ~370 in the strict field,
+// and k_pw_num is bound by VALU issue (6.4e9 instructions per 2^18-point call at the issue peak:
+// profiles/r03/g_pmc_lhs_witness_2p18_summary.txt).  Values stay in the ABI's domain (v 2^256) as long as every product has
+// ONE factor in the lazy field's own domain (v 2^261): (a 2^256)(b 2^261) / 2^261 = ab 2^256.  The domain points arrive in
+// both forms (k_domain), the per-node constants and the intermediate tA, tB are lifted with mul32 (32 v - q N, ~50
+// instructions, no Montgomery product).  Sums are carry-normalised before they enter a product (limbs < 2^29; the value may be
+// any representative with |V| < 8N); the three results are canonicalised and packed back into 32-byte elements.
+typedef Field29<Fr29Params> L29;
+typedef L29::fe lfe;
+__device__ __forceinline__ void to_l(lfe& r, const fe& a) { L29::unpack(r, a.v); }
+// (p + y q)(r + y w) with y^2 = s; p, q in the ABI domain, r, w, s in the 2^261 domain: oa + y ob in the ABI domain
+__device__ __forceinline__ void rfmul29(lfe& oa, lfe& ob, const lfe& pp, const lfe& qq, const lfe& rr, const lfe& ww, const lfe& s) {
+  lfe m1, m2, m3, e, f;
+  L29::mul(m1, pp, rr); L29::mul(m2, qq, ww);
+  L29::add(e, pp, qq); L29::wnorm(e); L29::add(f, rr, ww); L29::wnorm(f); L29::mul(m3, e, f);
+  L29::sub(m3, m3, m1); L29::sub(ob, m3, m2); L29::wnorm(ob);
+  L29::mul(e, m2, s); L29::add(oa, m1, e); L29::wnorm(oa);
+}
+__device__ __forceinline__ void pw_numerators29(fe& A, fe& Bv, fe& den, bool& den_zero, bool divide, const fe& x32, const fe& s32,
+                                                const fe& La, const fe& Lb, const fe& Ra, const fe& Rb,
+                                                const fe& c0, const fe& c1, const fe& d0, const fe& lX, const fe& lZZ, const fe& rX, const fe& rZZ, const fe& scale) {
+  lfe xq, sq, la, lb, ra, rb, t;
+  to_l(xq, x32); to_l(sq, s32); to_l(la, La); to_l(lb, Lb); to_l(ra, Ra); to_l(rb, Rb);
+  lfe a, b, dn;
+  den_zero = false;
+  if (divide) {
+    lfe k0, k1, kd, l, tA, tB, tA2, tB2, u, zl, xl, zr, xr;
+    to_l(t, c0); L29::mul32(k0, t); to_l(t, c1); L29::mul32(k1, t); to_l(t, d0); L29::mul32(kd, t);     // the scaled line, 2^261 domain
+    L29::mul(l, k1, xq); L29::add(l, l, k0); L29::wnorm(l);               // c0 + c1 x
+    rfmul29(tA, tB, ra, rb, l, kd, sq);                                   // R.w * line (ABI domain)
+    L29::mul32(tA2, tA); L29::mul32(tB2, tB);
+    rfmul29(a, b, la, lb, tA2, tB2, sq);                                  // L.w * (..)
+    to_l(zl, lZZ); to_l(xl, lX); L29::mul(t, zl, xq); L29::sub(t, t, xl); // ZZ_L x - X_L (ABI domain)
+    to_l(u, rZZ); L29::mul32(zr, u); to_l(u, rX); L29::mul32(xr, u);
+    L29::mul(u, zr, xq); L29::sub(u, u, xr);                              // ZZ_R x - X_R (2^261 domain)
+    L29::mul(dn, t, u);
+    L29::canon(dn);
+    den_zero = L29::limbs_zero(dn);
+    L29::pack(den.v, dn);
+  } else {
+    lfe ra2, rb2, sc, tq;
+    L29::mul32(ra2, ra); L29::mul32(rb2, rb);
+    rfmul29(a, b, la, lb, ra2, rb2, sq);
+    to_l(tq, scale); L29::mul32(sc, tq);
+    L29::mul(a, a, sc); L29::mul(b, b, sc);                               // 1/N of the inverse transform (and the reuse scale)
+    F::set_one(den);
+  }
+  L29::canon(a); L29::pack(A.v, a);
+  L29::canon(b); L29::pack(Bv.v, b);
+}
+
+// pass A: one thread per slot// pass A: one thread per slot (and one per node for the extra slot x = 0 of wrap mode, gid >= nnodes * N): numerators
 // into the L.a / L.b slots, the denominator into the R.b slot.  Nothing here depends on a neighbouring slot, so the loads
 // of a whole wave are in flight together (the one-kernel version walked a thread's slots one after the other at 190
 // VGPRs, two waves per SIMD).
+template <bool LAZY /* the products in the lazy 29-bit field (pw_numerators29: A/B variant, no faster) instead of the strict field; a template
+                       parameter: with both paths in one kernel the strict one lost 4 % to the larger register footprint */>
 __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN,
                                                 const u32* __restrict__ XS, const u32* __restrict__ consts /* [0]: curve b, [8]: 1/N, [16]: g */,
                                                 u32* __restrict__ stats, u32* __restrict__ c0in /* wrap mode, else null; [3][k] receives the extra slot's denominator */,
@@ -595,6 +654,7 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
                                                 const u32* __restrict__ odd /* reuse mode (else null): the children on the odd half, [q][node][N/2] */,
                                                 const u32* __restrict__ evprev /* the level below's transform buffer: quotient values (times 1/(N/2)) on the even half */,
                                                 const u32* __restrict__ evexc /* passed-through children on the even half, [2 tree + part][N/2] */, u32 nn_prev) {
+  constexpr bool lazy = LAZY;
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 per = (u64)nnodes << logN;
@@ -635,7 +695,10 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
     }
   } else if (kept) { fe sc; ld(sc, consts + (kept == 2 ? 48 : 40)); F::mul(scale, scale, sc); }
   fe x, sv, La, Lb, Ra, Rb, A, Bv, den;
-  if (extra) { F::set_zero(x); ld(sv, consts); }                         // x = 0: 0^3 + b
+  if (extra) {                                                           // x = 0: 0^3 + b
+    F::set_zero(x); ld(sv, consts);
+    if (lazy) { fe b5 = sv; for (int d = 0; d < 5; d++) F::add(b5, b5, b5); sv = b5; }
+  } else if (lazy) { const u32* XS32 = XS + ((size_t)16 << logN); ld(x, XS32 + (size_t)i * 16); ld(sv, XS32 + (size_t)i * 16 + 8); }   // 32 x_i, 32 (x_i^3 + b): the 2^261 domain
   else { ld(x, XS + (size_t)i * 16); ld(sv, XS + (size_t)i * 16 + 8); }  // x_i, x_i^3 + b (= y^2)
   if (odd == nullptr || extra) { ld(La, sLa); ld(Lb, sLb); ld(Ra, sRa); ld(Rb, sRb); }
   else {
@@ -655,8 +718,10 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
       }
     }
   }
-  pw_numerators(A, Bv, den, divide, x, sv, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, scale);
-  if (divide && F::is_zero(den)) { atomicOr(&stats[extra ? STAT_ZERO0 : STAT_ZERODEN], 1u); F::set_one(den); }
+  bool den_zero = false;
+  if constexpr (LAZY) pw_numerators29(A, Bv, den, den_zero, divide, x, sv, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, scale);
+  else { pw_numerators(A, Bv, den, divide, x, sv, La, Lb, Ra, Rb, c0, c1, d0, lX, lZZ, rX, rZZ, scale); den_zero = divide && F::is_zero(den); }
+  if (divide && den_zero) { atomicOr(&stats[extra ? STAT_ZERO0 : STAT_ZERODEN], 1u); F::set_one(den); }
   if (extra) {
     st(c0out + ((size_t)0 * nnodes + k) * 8, A); st(c0out + ((size_t)1 * nnodes + k) * 8, Bv);
     if (divide) st(sRb, den);

@@ -109,7 +109,7 @@ struct lemsm_ctx {
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
   long opt_host_threads = 0;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -1571,6 +1571,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "ws_canary")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_ws_canary = value; }
   else if (!strcmp(name, "dw_kb")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_kb = value; }
   else if (!strcmp(name, "dw_fuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_fuse = value; }
+  else if (!strcmp(name, "dw_pw_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_pw_lazy = value; }
   else if (!strcmp(name, "dw_reuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_reuse = value; }
   else if (!strcmp(name, "dw_wrap")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_wrap = value; }
   else if (!strcmp(name, "ntt_tiled")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_ntt_tiled = value; }

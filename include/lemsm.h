@@ -106,7 +106,8 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    stage: A/B knob), "dw_kb" (divisor witness: slots per thread of the batched-inversion kernels, 8..64; 0 = auto),
    "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
    input from the coefficient arrays and the last inverse pass scatters into them; 2 = separate load / store kernels:
-   A/B knob), "dw_reuse" (divisor witness: 0 = a level transforms its children onto the odd half of its domain only and reads the even half from the level
+   A/B knob), "dw_pw_lazy" (divisor witness: 1 = the pointwise numerators in the lazy 29-bit field -- 12 cheaper products, paid back by the
+   conversions around them: measured no faster; 0 = strict field: A/B knob), "dw_reuse" (divisor witness: 0 = a level transforms its children onto the odd half of its domain only and reads the even half from the level
    below's evaluations, 2 = whole transforms: A/B knob), "dw_wrap" (divisor witness: 0 = levels whose longest part
    has 2^k + 1 coefficients run on 2^k-point transforms, the folded top coefficient recovered from the value at x = 0;
    2 = always the next power of two: A/B knob), "ws_canary" (1 = debug: every sub-buffer of the MSM workspace is followed by a 256-byte guard that is

@@ -1182,6 +1182,27 @@ def test_divisor_witness_child_evaluation_reuse_equals_whole_transforms(ctx, n):
         assert res[0][3] >= 2, res[0][3]
 
 
+@pytest.mark.parametrize("n", [2, 7, 64, 1000, 3000, 9001])
+def test_divisor_witness_lazy_field_numerators_equal_strict_field(ctx, n):
+    """option dw_pw_lazy: the pointwise numerators / denominators in the lazy 29-bit field give the witness of the
+    strict-field formulas (the default), coefficient for coefficient; with an identity and a repeated point in the list (product mode, doubling)"""
+    g = pyref.GRUMPKIN
+    q = cref.gen_points(g.cid, 1850 + n, 1)[0]
+    rows = ctx.gen_walk(g.cid, q, n).download(np.uint64).reshape(-1, 8).copy()
+    if n >= 7:
+        rows[3] = 0; rows[n - 2] = rows[0]
+    res = []
+    try:
+        for mode in (0, 1):
+            ctx.set_option("dw_pw_lazy", mode)
+            a, b, outp = ctx.divisor_witness(api.GRUMPKIN, rows, False, True)
+            res.append((a.copy(), b.copy(), outp.copy()))
+    finally:
+        ctx.set_option("dw_pw_lazy", 0)
+    assert res[0][0].shape == res[1][0].shape and res[0][1].shape == res[1][1].shape
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
+
+
 def test_divisor_witness_batch_reuse_with_ragged_trees(ctx):
     """a forest of trees of different shapes (every kind of ragged right edge at once) with and without reuse"""
     g = pyref.GRUMPKIN
