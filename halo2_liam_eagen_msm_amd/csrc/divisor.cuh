@@ -504,6 +504,150 @@ __global__ __launch_bounds__(256) void k_ntt_tile(u32* __restrict__ buf, u64 tot
   }
 }
 
+// A/B variant (option dw_ntt_lazy = 1; measured 1 % SLOWER than k_ntt_tile, profiles/r03/l_ntt_lazy_field_ab.txt): the same pass
+// with the butterflies in the lazy 9 x 29-bit field (field29.cuh).  The transforms are bound by VALU issue
+// (profiles/r03/g_pmc_lhs_witness_2p18_summary.txt: 85 % of the issue peak), but this file's strict product is already 128
+// 64-bit multiply-adds + ~120 adds (disassembly: 768 v_mad_u64_u32 for the 6 products of k_ntt_tile<false, 0>) against the
+// lazy one's 162 + ~50, and the lazy butterfly pays two carry passes and a twiddle unpack on top: 3073 VALU instructions
+// against 2315 in the same kernel body.  Kept because it pins the strict kernel's buffers bit for bit (tests).
+// The elements stay in the ABI's domain (v 2^256) because the twiddles come from a second table in the lazy field's own
+// domain (W32 = 32 W: (a 2^256)(w 2^261) / 2^261 = a w 2^256).  A tile is unpacked into 9 signed limbs when it is loaded
+// (36 KB of LDS instead of 32) and canonicalised and packed when it is stored, so every pass reads and writes the same
+// 32-byte canonical elements as the strict kernel: bit-identical buffers.
+// Ranges.  Everything parked in LDS has normalised limbs.  Forward (decimation in frequency) x = u + v doubles the
+// bound on |V| per stage and the product's operand is the difference u - v: with a canonical twiddle the product
+// tolerates |u - v| < 128N, so the sums are pulled back below 2N (reduce_small, ~40 instructions) before a pair of
+// stages whenever the bound has passed 32N -- once in a ten-stage pass.  Inverse (decimation in time) x, y = u +- v w grow
+// by 2N per stage: 21N after ten.  Before canon() (|V| < 8N) the store reduces once more where the bound is above 4N.
+typedef Field29<Fr29Params> NL29;
+template <bool INV, int IO>
+__global__ __launch_bounds__(256) void k_ntt_tile_lz(u32* __restrict__ buf, u64 total, u32 logN, u32 lo, u32 S,
+                                                     const u32* __restrict__ W32, u32 log_half_max, TileIO io, const u32* __restrict__ src) {
+  typedef NL29::fe lf;
+  __shared__ i32 sm[9][1024];
+  const u32 tid = threadIdx.x;
+  const u32 TW = lo ? (1024u >> S) : 1u;
+  const u32 logTW = lo ? (10u - S) : 0u;
+  u64 base; u32 Lfull0 = 0;
+  if (lo == 0) base = (u64)blockIdx.x * 1024u;
+  else {
+    const u32 hi1 = lo + S;
+    const u32 lgroups = 1u << (lo - logTW);
+    const u64 b = blockIdx.x;
+    const u32 Lg = (u32)(b % lgroups); const u64 rest = b / lgroups;
+    base = (rest << hi1) + ((u64)Lg << logTW);
+    Lfull0 = Lg << logTW;
+  }
+  auto gidx = [&](u32 e) -> u64 { return lo == 0 ? base + e : base + ((u64)(e >> logTW) << lo) + (e & (TW - 1)); };
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 e = tid + 256u * q;
+    const u64 g = gidx(e);
+    fe v; F::set_zero(v);
+    if (g < total) {
+      if (IO == 1) tile_load_coeff(v, io, g, logN);
+      else if (IO == 3) tile_load_odd(v, io, g, logN);
+      else if (IO == 4) tile_load_even_exc(v, io, g, logN);
+      else ld(v, src + g * 8);
+    }
+    lf t; NL29::unpack(t, v.v);
+#pragma unroll
+    for (int l = 0; l < 9; l++) sm[l][e] = t.l[l];
+  }
+  __syncthreads();
+  auto tw_of = [&](lf& w, u32 j, u32 tw, u32 ls) {
+    const u32 logm = lo + ls;
+    const u32 r = lo == 0 ? (j & ((1u << ls) - 1)) : (((j & ((1u << ls) - 1)) << lo) + Lfull0 + tw);
+    const u32 t = r << (log_half_max - logm), half_max = 1u << log_half_max;
+    fe p;
+    if (!INV || t == 0) { ld(p, W32 + (size_t)t * 8); NL29::unpack(w, p.v); }
+    else { ld(p, W32 + (size_t)(half_max - t) * 8); lf q; NL29::unpack(q, p.v); NL29::neg(w, q); }   // omega^-t = -omega^(Nmax/2 - t)
+  };
+  auto lds_get = [&](lf& v, u32 e) {
+#pragma unroll
+    for (int l = 0; l < 9; l++) v.l[l] = sm[l][e];
+  };
+  auto lds_put = [&](u32 e, const lf& v) {
+#pragma unroll
+    for (int l = 0; l < 9; l++) sm[l][e] = v.l[l];
+  };
+  auto bfly = [&](lf& u, lf& v, const lf& w) {
+    lf x, y;
+    if (!INV) { NL29::add(x, u, v); NL29::wnorm(x); NL29::sub(y, u, v); NL29::mul(v, y, w); u = x; }
+    else { lf t; NL29::mul(t, v, w); NL29::add(x, u, t); NL29::wnorm(x); NL29::sub(y, u, t); NL29::wnorm(y); u = x; v = y; }
+  };
+  u32 bound = 1;                                     // |V| < bound N for everything in LDS (uniform)
+  auto single = [&](u32 ls) {
+    const bool red = !INV && bound > 64;
+#pragma unroll
+    for (u32 q = 0; q < 2; q++) {
+      const u32 bb = tid + 256u * q;
+      const u32 tw = bb & (TW - 1), p = bb >> logTW;
+      const u32 j0 = ((p >> ls) << (ls + 1)) + (p & ((1u << ls) - 1));
+      const u32 e0 = (j0 << logTW) + tw, e1 = e0 + ((1u << ls) << logTW);
+      lf w; tw_of(w, j0, tw, ls);
+      lf u, v; lds_get(u, e0); lds_get(v, e1);
+      if (red) { lf t; NL29::reduce_small(t, u); u = t; NL29::reduce_small(t, v); v = t; }
+      bfly(u, v, w);
+      lds_put(e0, u); lds_put(e1, v);
+    }
+    if (red) bound = 2;
+    bound = INV ? bound + 2 : 2 * bound;
+    __syncthreads();
+  };
+  auto pair = [&](u32 b) {
+    const u32 tw = tid & (TW - 1), p = tid >> logTW;
+    const u32 j00 = ((p >> b) << (b + 2)) | (p & ((1u << b) - 1));
+    const u32 j01 = j00 + (1u << b), j10 = j00 + (2u << b), j11 = j00 + (3u << b);
+    const u32 e0 = (j00 << logTW) + tw, e1 = (j01 << logTW) + tw, e2 = (j10 << logTW) + tw, e3 = (j11 << logTW) + tw;
+    lf x0, x1, x2, x3, wl, wh0, wh1;
+    lds_get(x0, e0); lds_get(x1, e1); lds_get(x2, e2); lds_get(x3, e3);
+    if (!INV && bound > 32) {
+      lf t; NL29::reduce_small(t, x0); x0 = t; NL29::reduce_small(t, x1); x1 = t; NL29::reduce_small(t, x2); x2 = t; NL29::reduce_small(t, x3); x3 = t;
+      bound = 2;
+    }
+    tw_of(wl, j00, tw, b); tw_of(wh0, j00, tw, b + 1); tw_of(wh1, j01, tw, b + 1);
+    if (!INV) { bfly(x0, x2, wh0); bfly(x1, x3, wh1); bfly(x0, x1, wl); bfly(x2, x3, wl); }
+    else { bfly(x0, x1, wl); bfly(x2, x3, wl); bfly(x0, x2, wh0); bfly(x1, x3, wh1); }
+    lds_put(e0, x0); lds_put(e1, x1); lds_put(e2, x2); lds_put(e3, x3);
+    bound = INV ? bound + 4 : 4 * bound;
+    __syncthreads();
+  };
+  if (!INV) {
+    int ls = (int)S - 1;
+    for (; ls >= 1; ls -= 2) pair((u32)ls - 1);
+    if (ls == 0) single(0);
+  } else {
+    u32 ls = 0;
+    for (; ls + 1 < S; ls += 2) pair(ls);
+    if (ls < S) single(ls);
+  }
+#pragma unroll
+  for (u32 q = 0; q < 4; q++) {
+    const u32 e = tid + 256u * q;
+    const u64 g = gidx(e);
+    if (g < total) {
+      lf t;
+#pragma unroll
+      for (int l = 0; l < 9; l++) t.l[l] = sm[l][e];
+      if (bound > 4) { lf r; NL29::reduce_small(r, t); t = r; }
+      NL29::canon(t);
+      fe v; NL29::pack(v.v, t);
+      if (IO == 2) tile_store_coeff(v, io, g, logN); else st(buf + g * 8, v);
+    }
+  }
+}
+
+// W32[t] = 32 W[t] (the twiddles in the lazy field's own domain, canonical)
+__global__ __launch_bounds__(256) void k_times32(const u32* __restrict__ W, u32 n, u32* __restrict__ W32) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  fe w; ld(w, W + (size_t)i * 8);
+#pragma unroll
+  for (int d = 0; d < 5; d++) F::add(w, w, w);
+  st(W32 + (size_t)i * 8, w);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // one level: load (zero-padded children into the transform buffer), pointwise, store
 // buffer layout: seq (q * nnodes + k), q = 0: L.a, 1: L.b, 2: R.a, 3: R.b; results overwrite q = 0 (a) and 1 (b)
@@ -653,14 +797,16 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
                                                 u32* __restrict__ c0out,
                                                 const u32* __restrict__ odd /* reuse mode (else null): the children on the odd half, [q][node][N/2] */,
                                                 const u32* __restrict__ evprev /* the level below's transform buffer: quotient values (times 1/(N/2)) on the even half */,
-                                                const u32* __restrict__ evexc /* passed-through children on the even half, [2 tree + part][N/2] */, u32 nn_prev) {
+                                                const u32* __restrict__ evexc /* passed-through children on the even half, [2 tree + part][N/2] */, u32 nn_prev,
+                                                u32 k0, u32 kn /* this launch covers the nodes [k0, k0 + kn) (a level runs as two halves on two queues) */) {
   constexpr bool lazy = LAZY;
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 per = (u64)nnodes << logN;
-  const bool extra = gid >= per;
-  if (extra && (c0in == nullptr || gid >= per + nnodes)) return;
-  const u32 k = extra ? (u32)(gid - per) : (u32)(gid >> logN), i = extra ? 0u : ((u32)gid & (N - 1));
+  const u64 perl = (u64)kn << logN;
+  const bool extra = gid >= perl;
+  if (extra && (c0in == nullptr || gid >= perl + kn)) return;
+  const u32 k = k0 + (extra ? (u32)(gid - perl) : (u32)(gid >> logN)), i = extra ? 0u : ((u32)gid & (N - 1));
   const Plan& pl = plan[k];
   if (pl.mode == MODE_PASS) return;
   u32* sLa = buf + (((size_t)k << logN) + i) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;
@@ -676,7 +822,7 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
   // The scaled line coefficients are the same for every slot of a node's half: where a whole block lies inside one
   // (N >= 512), three lanes compute them once for the block instead of every lane for itself (6 of ~18 products per slot)
   __shared__ u32 shc[3][8];
-  const bool uni = logN >= 9 && ((u64)blockIdx.x + 1) * 256 <= per;
+  const bool uni = logN >= 9 && ((u64)blockIdx.x + 1) * 256 <= perl;
   if (divide) {
     ld(lX, pl.lX); ld(lZZ, pl.lZZ); ld(rX, pl.rX); ld(rZZ, pl.rZZ);
     if (uni) {
@@ -738,11 +884,11 @@ __global__ __launch_bounds__(256) void k_pw_num(u32* __restrict__ buf, const Pla
 // RK * (slots per thread) elements instead of one per thread.  k_pw_apply: backwards over the same slots, the inverse of
 // every denominator onto its numerators.  Thread 0 of a node also owns the node's extra slot (wrap mode).
 __global__ __launch_bounds__(256) void k_pw_prefix(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
-                                                   const u32* __restrict__ c0in, u32* __restrict__ roots) {
+                                                   const u32* __restrict__ c0in, u32* __restrict__ roots /* of this launch's nodes */, u32 k0, u32 kn) {
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (u64)nnodes * stride) return;
-  const u32 k = (u32)(gid / stride), c = (u32)(gid - (u64)k * stride);
+  if (gid >= (u64)kn * stride) return;
+  const u32 kl = (u32)(gid / stride), k = k0 + kl, c = (u32)(gid - (u64)kl * stride);
   fe run; F::set_one(run);
   if (plan[k].mode == MODE_DIVIDE) {
     const size_t per = (size_t)nnodes << logN;
@@ -778,11 +924,12 @@ __global__ __launch_bounds__(256) void k_pw_rootinv(u32* __restrict__ roots, u32
 }
 
 __global__ __launch_bounds__(256) void k_pw_apply(u32* __restrict__ buf, const Plan* __restrict__ plan, u32 nnodes, u32 logN, u32 stride /* threads per node */,
-                                                  const u32* __restrict__ c0in, u32* __restrict__ c0out, const u32* __restrict__ rootinv) {
+                                                  const u32* __restrict__ c0in, u32* __restrict__ c0out, const u32* __restrict__ rootinv /* of this launch's nodes */,
+                                                  u32 k0, u32 kn) {
   const u32 N = 1u << logN;
   const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (u64)nnodes * stride) return;
-  const u32 k = (u32)(gid / stride), c = (u32)(gid - (u64)k * stride);
+  if (gid >= (u64)kn * stride) return;
+  const u32 kl = (u32)(gid / stride), k = k0 + kl, c = (u32)(gid - (u64)kl * stride);
   if (plan[k].mode != MODE_DIVIDE) return;
   const size_t per = (size_t)nnodes << logN;
   u32* sLa = buf + (((size_t)k << logN)) * 8; u32* sLb = sLa + per * 8; u32* sRa = sLb + per * 8; u32* sRb = sRa + per * 8;

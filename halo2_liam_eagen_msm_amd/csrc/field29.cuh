@@ -204,6 +204,20 @@ struct Field29 {
       else r.l[i] = (i32)t;
     }
   }
+  // a - q N with q = round-to-zero(a / N) estimated from the top limb: congruent to a, |r| < 2N, limbs normalised (~40
+  // instructions).  a: normalised limbs, |a| < 2^261 (the transforms' sums grow by a factor of two per stage; a product
+  // with a canonical factor tolerates |a| < 128N: |a w| / 2^261 + N < 2N).
+  static __device__ __forceinline__ void reduce_small(fe& r, const fe& a) {
+    const float inv = 1.0f / (float)P::N[8];
+    i32 q = (i32)((float)a.l[8] * inv);            // |a/N - q| < 1 + 2^-13
+    i64 t = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      t += (i64)a.l[i] - (i64)q * P::N[i];
+      if (i < 8) { r.l[i] = (i32)t & MASK; t >>= 29; }
+      else r.l[i] = (i32)t;
+    }
+  }
   static __device__ __forceinline__ void set_c266(fe& r) {
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = P::C266[i];

@@ -19,6 +19,7 @@
 #include <memory>
 #include "kernels.cuh"
 #include "rccl_dyn.hpp"
+#include "roctx_dyn.hpp"
 #include "divisor.cuh"
 #include <rocprim/rocprim.hpp>
 #include <chrono>
@@ -90,6 +91,7 @@ struct lemsm_ctx {
   hipStream_t stream_sort = nullptr;   // digit + sort passes of the next window group (high priority)
   hipStream_t stream_tail = nullptr;   // edge-record levels + pyramid of the previous group
   std::vector<hipEvent_t> evpool;
+  hipEvent_t dw_ev[2] = {nullptr, nullptr};      // divisor witness: the two half-level pointwise chains (divisor_abi.inc)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [4]: the digit pass's error words have reached the host
   DevBuf ws;        // workspace arena
   DevBuf in_s;      // staged scalars (host-pointer entries)
@@ -109,7 +111,7 @@ struct lemsm_ctx {
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
   long opt_host_threads = 0;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0, opt_dw_halves = 0, opt_dw_ntt_lazy = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -508,6 +510,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
 
   // k_pyramid_first2 recognises empty buckets from bucket_start[]: with it only the counters are zeroed, not the bucket sums
   const bool first2 = L >= 5 && ctx->opt_pyr_first2 == 1;
+  RoctxRange rg_group("lemsm: window group (digits + sort + accumulate + tail enqueued)");
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, first2 ? w.zero_bytes_counters : w.zero_bytes, st));
   for (size_t g : w.guards) HIPCHK(ctx, hipMemsetAsync(ws_base + g, 0xA5, WS_GUARD, st));
 
@@ -565,6 +568,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
 
   // edge-record merge (kernels_ec.cuh): pairs at once, longer buckets through the size-class queues
   {
+    RoctxRange rg_tail("lemsm: edge-record merge");
     const u32 sc = abi ? 1u : 0u;
     char* bsum = w.arena + (size_t)ar.bucket_off * ptb;
     hipLaunchKernelGGL((k_merge_pairs<G>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, sc, mq, d_bstart, w.meta, w.rec_key, w.rec_pt, bsum, w.mq_cnt, w.mq_items);
@@ -573,6 +577,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     hipLaunchKernelGGL((k_merge_waves<G>), dim3(std::min(ctx->num_cus, std::max(1u, (mq.capM + mq.capL + 3) / 4))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.rec_pt, w.mq_partial, bsum, w.mq_cnt);
     hipLaunchKernelGGL((k_merge_final<G>), dim3(std::min(ctx->num_cus, std::max(1u, (mq.capF + 3) / 4))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.mq_partial, bsum, w.mq_cnt);
   }
+  RoctxRange rg_pyr("lemsm: bucket-reduction pyramid");
   // bucket reduction pyramid: one launch per step while a step is wide, then all remaining steps (and the copy of
   // U_{L-1}) in one launch of one block per window (k_pyramid_tail)
   {
@@ -866,6 +871,7 @@ size_t first_bad_scalar(const WinRun& wr, const u32* slots) {
 // Reads back this call's records (wr.d_out) together with its status slots, waits, and turns the digit pass's flags into
 // the reference's panic sites.  raw_bytes = 0: the status slots only (one-GPU rehearsal of a rank).
 int run_windows_finish(lemsm_ctx* ctx, const WinRun& wr, const char* d_raw, size_t raw_bytes, std::vector<char>& raw) {
+  RoctxRange rg_fin("lemsm: read-back and wait");
   hipStream_t s_tail = records_stream(ctx);
   raw.resize(raw_bytes);
   const size_t err_bytes = wr.ng ? wr.err_cap : 0;
@@ -907,6 +913,7 @@ void sum_slab_records(lemsm_ctx* ctx, const char* raw, size_t out_slab, size_t n
                       bool fold = false /* leave the nw window sums S_w = total + sum_l 2^l U_l instead of the records */) {
   typedef host::HG<P64> HGp;
   const size_t ptb = G::PT_BYTES;
+  RoctxRange rg_host("lemsm: host fold of the window records");
   host_out.assign(fold ? (size_t)nw : (size_t)nw * (L + 1), HGp::identity());
   host_parallel(ctx, (int)nw, [&](int w) {        // one job per window: its L + 1 records of every slab (and their Horner fold)
     std::vector<host::pt> tmp(L + 1), acc(L + 1);
@@ -1548,6 +1555,7 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   for (DevBuf* b : {&ctx->ws, &ctx->in_s, &ctx->in_p, &ctx->in_aux, &ctx->gather, &ctx->fail_buf, &ctx->dw_tab, &ctx->dw_arena, &ctx->dw_tmp}) if (b->p) (void)hipFree(b->p);
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  for (int i = 0; i < 2; i++) if (ctx->dw_ev[i]) (void)hipEventDestroy(ctx->dw_ev[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1572,6 +1580,8 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "dw_kb")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_kb = value; }
   else if (!strcmp(name, "dw_fuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_fuse = value; }
   else if (!strcmp(name, "dw_pw_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_pw_lazy = value; }
+  else if (!strcmp(name, "dw_halves")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_halves = value; }
+  else if (!strcmp(name, "dw_ntt_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_ntt_lazy = value; }
   else if (!strcmp(name, "dw_reuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_reuse = value; }
   else if (!strcmp(name, "dw_wrap")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_wrap = value; }
   else if (!strcmp(name, "ntt_tiled")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_ntt_tiled = value; }

@@ -1203,6 +1203,31 @@ def test_divisor_witness_lazy_field_numerators_equal_strict_field(ctx, n):
     assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
 
 
+@pytest.mark.parametrize("knob", ["dw_ntt_lazy", "dw_halves"])
+@pytest.mark.parametrize("n", [2, 7, 64, 1000, 3000, 9001, 40000])
+def test_divisor_witness_ab_knobs_equal_default(ctx, knob, n):
+    """options dw_ntt_lazy (transform butterflies in the lazy 29-bit field: sums reduced mid-pass, canonical on store) and
+    dw_halves (a level's pointwise chain as two halves of its nodes on two queues) give the default path's witness,
+    coefficient for coefficient; lists long enough for strided transform passes (2^11 and above) and, as a batch of two
+    trees, for levels with several nodes at every size"""
+    g = pyref.GRUMPKIN
+    q = cref.gen_points(g.cid, 1950 + n, 1)[0]
+    rows = ctx.gen_walk(g.cid, q, n).download(np.uint64).reshape(-1, 8).copy()
+    if n >= 7:
+        rows[3] = 0; rows[n - 2] = rows[0]
+    lists = [rows, rows[: max(1, n // 3)]]
+    res = []
+    try:
+        for mode in (0, 1):
+            ctx.set_option(knob, mode)
+            res.append(ctx.divisor_witness_batch(api.GRUMPKIN, lists, False, True))
+    finally:
+        ctx.set_option(knob, 0)
+    for t in range(2):
+        for part in range(3):
+            assert np.array_equal(np.asarray(res[0][t][part]), np.asarray(res[1][t][part])), (t, part)
+
+
 def test_divisor_witness_batch_reuse_with_ragged_trees(ctx):
     """a forest of trees of different shapes (every kind of ragged right edge at once) with and without reuse"""
     g = pyref.GRUMPKIN
