@@ -32,10 +32,10 @@ struct ArenaLayout {
   u32 bucket_off, apyr_off, rbuf_off, out_off, total_points;
 };
 
-inline ArenaLayout make_arena(u32 NBpad, u32 nbp, u32 gw, u32 L) {
+inline ArenaLayout make_arena(u32 NBpad, u32 nbp, u32 gw, u32 L, u32 nba = 1 /* bucket areas: one per slab when the slabs of a call share one tail */) {
   ArenaLayout a;
   a.bucket_off = 0;
-  a.apyr_off = NBpad;
+  a.apyr_off = NBpad * nba;
   a.rbuf_off = a.apyr_off + nbp * gw;
   a.out_off = a.rbuf_off + nbp * gw;
   a.total_points = a.out_off + (L + 1) * gw;

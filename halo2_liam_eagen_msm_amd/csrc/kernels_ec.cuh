@@ -376,6 +376,27 @@ __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tas
   pyr_item<G>(tk, w, i, arena);
 }
 
+// One tail per call: with several slabs of points every slab sorts and accumulates into a bucket area of its own (the
+// sorted entries, records and queues of the workspace are reused slab after slab), and before the ONE pyramid of the call
+// this kernel adds the areas bucket by bucket into the first.  `scaled_mask` bit k: slab k ran the ABI form of k_accum1
+// (its sums are (X, Y, 32 ZZ, 32 ZZZ)); the result is plain, empty buckets (all-zero slots) stay the identity.
+template <class G>
+__global__ __launch_bounds__(256) void k_sum_slabs(char* __restrict__ bucket_sum, u32 nbuckets, u32 nslabs, u32 scaled_mask) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nbuckets) return;
+  typename G::pt acc, q;
+  G::load(acc, bucket_sum + (size_t)i * G::PT_BYTES);
+  if (scaled_mask & 1u) G::unscale(acc);
+#pragma unroll 1
+  for (u32 k = 1; k < nslabs; k++) {
+    G::load(q, bucket_sum + ((size_t)k * nbuckets + i) * G::PT_BYTES);
+    if ((scaled_mask >> k) & 1u) G::unscale(q);
+    G::add(acc, q);
+  }
+  G::store(bucket_sum + (size_t)i * G::PT_BYTES, acc);
+}
+
+
 // Steps 1 and 2 of the pyramid in one pass over the bucket sums.  A step-per-launch pyramid moves every point of a level
 // through HBM twice (written by one launch, read by the next) and its first steps are as much bandwidth- as
 // arithmetic-bound (step 1 of a 2^24-point MSM: 354 MB in 111 us); the first two steps are 3/4 of all the additions.

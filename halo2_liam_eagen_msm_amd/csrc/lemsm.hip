@@ -111,7 +111,7 @@ struct lemsm_ctx {
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
   long opt_host_threads = 0;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0, opt_dw_halves = 0, opt_dw_ntt_lazy = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0, opt_dw_halves = 0, opt_dw_ntt_lazy = 0, opt_slab_tail = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -318,7 +318,7 @@ GroupWs carve(char* base, const GroupPlan& pl, const ArenaLayout& ar, const MqLa
   size_t o_bin_total = take(MAX_BINS * 4), o_bin_cursor = take(MAX_BINS * 4);
   size_t o_bcount = take((size_t)NBpad * 4), o_bcursor = take((size_t)NBpad * 4);
   size_t o_arena = take((size_t)ar.total_points * ptb);
-  size_t zend = o_arena + (size_t)NBpad * ptb;   // only the bucket sums need zeroing
+  size_t zend = o_arena + (size_t)(ar.apyr_off - ar.bucket_off) * ptb;   // only the bucket sums need zeroing (every slab's area when the slabs share one tail)
   w.zero_bytes_counters = o_arena - z0;
   size_t o_bin_start = take((MAX_BINS + 1) * 4), o_tile_prefix = take((MAX_BINS + 1) * 4), o_meta = take(64);
   size_t o_bstart = take(((size_t)NBpad + 1) * 4);
@@ -474,20 +474,24 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
               bool abi /* d_points are in the C ABI's domain: k_accum1<.., true>, scaled outputs */,
               char* ws_base, char* d_out /* device, gw*(L+1)*PT_BYTES */, u32* d_slot /* device, this (slab, group)'s 64-byte status slot */, hipStream_t s_sort, hipStream_t s_acc,
               hipStream_t s_tail, hipEvent_t ev_sorted, hipEvent_t ev_acc0, hipEvent_t ev_acc1,
-              hipEvent_t ev_points /* null, or: the converted points become ready on another queue */ = nullptr) {
+              hipEvent_t ev_points /* null, or: the converted points become ready on another queue */ = nullptr,
+              u32 slab_k = 0, u32 nba = 1 /* > 1: the slabs of the call share one tail -- slab_k accumulates into its own bucket area, the
+              last one (slab_k == nba - 1) adds the areas up and runs the pyramid */, u32 scaled_mask = 0 /* bit k: slab k's sums are in the ABI form */) {
   // Three queues: the sort passes of this group may run while the previous group accumulates
   // (s_sort), the accumulate kernels of all groups run back to back (s_acc), and this group's
   // edge-record levels + pyramid overlap the next group's accumulation (s_tail).
   hipStream_t st = s_sort;
   u32 gw = pl.w1 - pl.w0;
   u32 NBpad = pl.nbins << pl.LB;
-  ArenaLayout ar = make_arena(NBpad, nbp, gw, L);
+  ArenaLayout ar = make_arena(NBpad, nbp, gw, L, nba);
+  const bool abi_pyr = nba > 1 ? false : abi;      // k_sum_slabs leaves plain sums
+  const bool last_slab = slab_k + 1 == nba;
   // pyramid task tables: built and uploaded once per plan shape, then reused
-  std::vector<u32> pkey = {NBpad, pl.nb, pl.nbw, nbp, L, gw, abi ? 1u : 0u};
+  std::vector<u32> pkey = {NBpad, pl.nb, pl.nbw, nbp, L, gw, abi_pyr ? 1u : 0u, nba};
   auto pit = ctx->pyr_cache.find(pkey);
   if (pit == ctx->pyr_cache.end()) {
     PyrCacheEntry ent;
-    ent.pp = make_pyr_plan(ar, pl.nb, pl.nbw, nbp, L, abi);
+    ent.pp = make_pyr_plan(ar, pl.nb, pl.nbw, nbp, L, abi_pyr);
     std::vector<PyrTask> flat;
     for (auto& s : ent.pp.steps) flat.insert(flat.end(), s.begin(), s.end());
     size_t tb = align_up(flat.size() * sizeof(PyrTask), 256);
@@ -509,9 +513,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     return fail(ctx, LEMSM_ERR_HIP, "internal: window-group plan exceeds a kernel limit (bins " + std::to_string(pl.nbins) + ", bins per window " + std::to_string(pl.BW) + ")");
 
   // k_pyramid_first2 recognises empty buckets from bucket_start[]: with it only the counters are zeroed, not the bucket sums
-  const bool first2 = L >= 5 && ctx->opt_pyr_first2 == 1;
+  const bool first2 = L >= 5 && ctx->opt_pyr_first2 == 1 && nba == 1;
   RoctxRange rg_group("lemsm: window group (digits + sort + accumulate + tail enqueued)");
-  HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, first2 ? w.zero_bytes_counters : w.zero_bytes, st));
+  // (shared tail: the first slab clears every slab's bucket area, the later ones only the counters)
+  HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, (first2 || slab_k > 0) ? w.zero_bytes_counters : w.zero_bytes, st));
   for (size_t g : w.guards) HIPCHK(ctx, hipMemsetAsync(ws_base + g, 0xA5, WS_GUARD, st));
 
   typename Prov::Dec dec;
@@ -549,7 +554,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   HIPCHK(ctx, hipEventRecord(ev_acc0, s_acc));
   {
     dim3 grid((pl.nthr1 + 255) / 256), blk(256);
-    char* bsum = w.arena + (size_t)ar.bucket_off * ptb;
+    char* bsum = w.arena + ((size_t)ar.bucket_off + (size_t)slab_k * NBpad) * ptb;
     // register-budget variant of the accumulate kernel (lazy field: 2, 3 or 4 waves per SIMD)
     int wps = G::CONVERTED_DOMAIN ? (ctx->opt_accum_waves ? (int)ctx->opt_accum_waves : 3) : 4;
     if constexpr (G::CONVERTED_DOMAIN) {
@@ -570,7 +575,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   {
     RoctxRange rg_tail("lemsm: edge-record merge");
     const u32 sc = abi ? 1u : 0u;
-    char* bsum = w.arena + (size_t)ar.bucket_off * ptb;
+    char* bsum = w.arena + ((size_t)ar.bucket_off + (size_t)slab_k * NBpad) * ptb;
     hipLaunchKernelGGL((k_merge_pairs<G>), dim3((pl.nthr1 + 255) / 256), dim3(256), 0, st, pl, sc, mq, d_bstart, w.meta, w.rec_key, w.rec_pt, bsum, w.mq_cnt, w.mq_items);
     // the host does not know the queue lengths: these kernels run one block per CU whose waves take the items in turns
     hipLaunchKernelGGL((k_merge_serial<G>), dim3(std::min(ctx->num_cus, std::max(1u, (mq.capS + mq.capM + 63) / 64))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.rec_pt, bsum);
@@ -578,9 +583,11 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     hipLaunchKernelGGL((k_merge_final<G>), dim3(std::min(ctx->num_cus, std::max(1u, (mq.capF + 3) / 4))), dim3(256), 0, st, sc, mq, w.mq_cnt, w.mq_items, w.mq_partial, bsum, w.mq_cnt);
   }
   RoctxRange rg_pyr("lemsm: bucket-reduction pyramid");
+  if (nba > 1 && last_slab)
+    hipLaunchKernelGGL((k_sum_slabs<G>), dim3((NBpad + 255) / 256), dim3(256), 0, st, w.arena + (size_t)ar.bucket_off * ptb, NBpad, nba, scaled_mask);
   // bucket reduction pyramid: one launch per step while a step is wide, then all remaining steps (and the copy of
   // U_{L-1}) in one launch of one block per window (k_pyramid_tail)
-  {
+  if (last_slab) {
     size_t toff = 0;
     u32 s_begin = 1;
     if (first2) {   // steps 1 + 2 in one pass over the bucket sums (k_pyramid_first2); the task tables take over at step 3
@@ -589,7 +596,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       fa.a2_off = ar.apyr_off + nbp / 2;          // offA(2)
       fa.r02_off = ar.rbuf_off + nbp / 4;         // offR(0, 2)
       fa.r11_off = ar.rbuf_off + nbp / 2;         // offR(1, 1)
-      fa.scaled = abi ? 1u : 0u;
+      fa.scaled = abi_pyr ? 1u : 0u;
       const u32 threads = gw * (nbp / 8);
       hipLaunchKernelGGL((k_pyramid_first2<G>), dim3((threads + 255) / 256), dim3(256), 0, st, fa, d_bstart, w.arena, w.mq_cnt);
       toff = pp.steps[0].size() + pp.steps[1].size();
@@ -616,7 +623,7 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, d_tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
       toff += tasks.size();
     }
-    const bool need_copy = !(L == 1 && abi);
+    const bool need_copy = !(L == 1 && abi_pyr);
     if (first_fused <= L) {
       PyrTailArgs ta; memset(&ta, 0, sizeof ta);
       ta.first = first_fused; ta.last = L;
@@ -630,8 +637,8 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     }
   }
   {
-    const u32 n16 = (u32)((size_t)gw * (L + 1) * ptb / 16);
-    hipLaunchKernelGGL(k_group_finish, dim3((n16 + 255) / 256), dim3(256), 0, st, (const uint4*)(w.arena + (size_t)ar.out_off * ptb), (uint4*)d_out, n16,
+    const u32 n16 = last_slab ? (u32)((size_t)gw * (L + 1) * ptb / 16) : 0u;   // (a slab that is not the call's last leaves its status slot only)
+    hipLaunchKernelGGL(k_group_finish, dim3(std::max(1u, (n16 + 255) / 256)), dim3(256), 0, st, (const uint4*)(w.arena + (size_t)ar.out_off * ptb), (uint4*)d_out, n16,
                        w.err, w.meta + META_CLOCK, w.mq_cnt, d_slot);
   }
   HIPCHK(ctx, hipGetLastError());
@@ -645,9 +652,9 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   return LEMSM_OK;
 }
 
-size_t group_ws_bytes(const lemsm_ctx* ctx, const GroupPlan& pl, u32 nbp, u32 L, size_t ptb, bool guard) {
+size_t group_ws_bytes(const lemsm_ctx* ctx, const GroupPlan& pl, u32 nbp, u32 L, size_t ptb, bool guard, u32 nba = 1) {
   u32 gw = pl.w1 - pl.w0;
-  ArenaLayout ar = make_arena(pl.nbins << pl.LB, nbp, gw, L);
+  ArenaLayout ar = make_arena(pl.nbins << pl.LB, nbp, gw, L, nba);
   GroupWs w = carve(nullptr, pl, ar, make_mq_layout(ctx, pl.nthr1), ptb, guard);
   return w.total + 4096;
 }
@@ -659,16 +666,23 @@ size_t group_ws_bytes(const lemsm_ctx* ctx, const GroupPlan& pl, u32 nbp, u32 L,
 // records [total, U_0..U_{L-1}] of windows wb.. of slab k (nw_pad windows' worth of room, unused tail zeroed).
 struct WinRun {
   size_t nslabs = 0, ng = 0, out_slab = 0, SLAB = 0, err_slot = 0;
+  size_t nrec = 0;         // record blocks: nslabs, or 1 when the slabs share one tail (shared_tail())
   size_t err_stride = 1;   // status slots per slab: nw_pad, the same on every rank whatever its own number of window groups
   size_t err_cap = 0;      // bytes of the status-slot area (nslabs x err_stride slots, rounded up)
   char* d_out = nullptr; char* d_err = nullptr;
   u32 nw = 0, nw_pad = 0, L = 0; size_t ptb = 0;
-  size_t send_bytes() const { return out_slab * nslabs; }
+  size_t send_bytes() const { return out_slab * nrec; }
   // multi-GPU: what one rank contributes to the all-gather -- its records, its status slots (so that every rank sees every
   // rank's non-canonical-scalar flags and all return the same status) and one 256-byte rank status (STATUS_BYTES)
   static constexpr size_t STATUS_BYTES = 256;
-  size_t send_total() const { return out_slab * nslabs + err_cap + STATUS_BYTES; }
+  size_t send_total() const { return out_slab * nrec + err_cap + STATUS_BYTES; }
 };
+
+// Several slabs, one tail: each slab accumulates into a bucket area of its own and the call runs ONE pyramid (k_sum_slabs)
+// and leaves ONE block of records, where the slabs would otherwise each pay the ~0.3 ms latency chain of the tail and the
+// host add their records (option slab_tail = 2: a tail per slab, as before).  Up to 8 slabs (8 x 75 MB of bucket areas
+// per window group at c = 16); a function of the call's arguments and options alone, so every rank decides alike.
+bool shared_tail(const lemsm_ctx* ctx, size_t nslabs) { return nslabs > 1 && nslabs <= 8 && ctx->opt_slab_tail != 2 && ctx->opt_groups <= 1; }
 
 // The part of run_windows_enqueue's bookkeeping that fixes what a rank sends in the exchange (device-pointer entries):
 // a function of the call's arguments and options alone, the same on every rank.
@@ -677,6 +691,7 @@ void win_sizes(const lemsm_ctx* ctx, size_t n, u32 nw_pad, u32 L, WinRun& wr) {
   const u32 slab_log = ctx->opt_slab_bits ? (u32)ctx->opt_slab_bits : MAX_SLAB_LOG;
   wr.SLAB = (size_t)1 << slab_log;
   wr.nslabs = n ? (n + wr.SLAB - 1) / wr.SLAB : 1;
+  wr.nrec = shared_tail(ctx, wr.nslabs) ? 1 : wr.nslabs;
   wr.ptb = G::PT_BYTES; wr.L = L; wr.nw_pad = nw_pad; wr.nw = 0; wr.ng = 0;
   wr.out_slab = align_up((size_t)std::max(nw_pad, 1u) * (L + 1) * wr.ptb, 256);
   wr.err_slot = 96; wr.err_stride = std::max<size_t>(nw_pad, 1);
@@ -712,6 +727,9 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   if (hs) slab_log = host_slab_log(ctx, n);
   const size_t SLAB = (size_t)1 << slab_log;
   const size_t nslabs = n ? (n + SLAB - 1) / SLAB : 1;
+  const bool shared = shared_tail(ctx, nslabs);
+  const u32 nba = shared ? (u32)nslabs : 1u;
+  const size_t nrec = shared ? 1 : nslabs;
   ctx->plan_slab_n = (u32)std::min(SLAB, n);
   u32 gmax = max_group_windows(ctx, nb, ctx->plan_slab_n, d);
   const size_t ptb = G::PT_BYTES;
@@ -731,8 +749,8 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
     u32 sn0 = (u32)std::min(SLAB, n), snl = (u32)(n - (nslabs - 1) * SLAB);
     for (u32 g0 = wb; g0 < we; g0 += gsz) {
       u32 g1 = std::min(we, g0 + gsz);
-      size_t bytes = group_ws_bytes(ctx, make_group_plan(ctx, sn0, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0);
-      if (snl != sn0) bytes = std::max(bytes, group_ws_bytes(ctx, make_group_plan(ctx, snl, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0));
+      size_t bytes = group_ws_bytes(ctx, make_group_plan(ctx, sn0, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0, nba);
+      if (snl != sn0) bytes = std::max(bytes, group_ws_bytes(ctx, make_group_plan(ctx, snl, c, nb, W, g0, g1, d), nbp, L, ptb, ctx->opt_ws_canary != 0, nba));
       groups.push_back({g0, g1, ws_total});
       ws_total += align_up(bytes + 8192, 256);     // (+ slack for the 16-entry rounding of the accumulate chunk, see make_group_plan)
     }
@@ -744,14 +762,14 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   const size_t err_bytes = align_up(nslabs * err_stride * ERR_SLOT, 256);
   size_t conv_bytes = G::CONVERTED_DOMAIN ? align_up(std::min(SLAB, n) * 64, 256) : 0;
   // sizes first (a rank that fails below still has to contribute a buffer of the agreed size to the collective)
-  wr.nslabs = nslabs; wr.ng = ng; wr.out_slab = out_slab; wr.SLAB = SLAB; wr.err_slot = ERR_SLOT; wr.err_stride = err_stride; wr.err_cap = err_bytes;
+  wr.nslabs = nslabs; wr.nrec = nrec; wr.ng = ng; wr.out_slab = out_slab; wr.SLAB = SLAB; wr.err_slot = ERR_SLOT; wr.err_stride = err_stride; wr.err_cap = err_bytes;
   wr.nw = nw; wr.nw_pad = nw_pad; wr.L = L; wr.ptb = ptb;
-  int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nslabs + err_bytes + WinRun::STATUS_BYTES + 4096);
+  int rc = reserve(ctx, ctx->ws, ws_total + conv_bytes + out_slab * nrec + err_bytes + WinRun::STATUS_BYTES + 4096);
   if (rc) return rc;
   char* ws_base = (char*)ctx->ws.p;
   char* d_conv = ws_base + ws_total;
   char* d_out = d_conv + conv_bytes;
-  char* d_err = d_out + out_slab * nslabs;
+  char* d_err = d_out + out_slab * nrec;
   wr.d_out = d_out; wr.d_err = d_err;
   while (ctx->evpool.size() < 3 * ng * nslabs + (hs ? nslabs : 0)) {
     hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e);
@@ -766,8 +784,9 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s_acc));
   ctx->t_accum_ms = 0; ctx->n_accum = 0;
   if (nw_pad != nw || n == 0 || nw == 0)      // record slots no kernel writes (a rank with fewer windows than the widest one) read as identities
-    HIPCHK(ctx, hipMemsetAsync(d_out, 0, out_slab * nslabs, s_acc));
+    HIPCHK(ctx, hipMemsetAsync(d_out, 0, out_slab * nrec, s_acc));
   HIPCHK(ctx, hipMemsetAsync(d_err, 0, err_bytes + WinRun::STATUS_BYTES, s_acc));   // status slots no group writes, and the rank status word (0 = ok)
+  u32 scaled_mask = 0;       // shared tail: which slabs accumulated in the ABI form (the ragged last slab may choose differently)
   for (size_t k = 0; k < nslabs && n && nw; k++) {
     const size_t s0 = k * SLAB;
     u32 sn = (u32)std::min(SLAB, n - s0);
@@ -816,8 +835,10 @@ int run_windows_enqueue(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 n
       pl.nstride = (u32)n;   // negabase digit matrix: d rows of n columns, whatever the slab (lhs_partial_t bounds n < 2^32)
       auto src = make_src(s0, sn);
       hipEvent_t* ev = ctx->evpool.data() + 3 * (k * ng + gi);
-      rc = run_group<G>(ctx, src, pl, nbp, L, pts, abi, ws_base + gr.off, d_out + k * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
-                        (u32*)(d_err + (k * err_stride + gi) * ERR_SLOT), s_sort, s_acc, s_tail, ev[0], ev[1], ev[2], gi == 0 ? ev_points : nullptr);
+      if (gi == 0 && abi) scaled_mask |= 1u << k;
+      rc = run_group<G>(ctx, src, pl, nbp, L, pts, abi, ws_base + gr.off, d_out + (shared ? 0 : k) * out_slab + (size_t)(gr.g0 - wb) * (L + 1) * ptb,
+                        (u32*)(d_err + (k * err_stride + gi) * ERR_SLOT), s_sort, s_acc, s_tail, ev[0], ev[1], ev[2], gi == 0 ? ev_points : nullptr,
+                        shared ? (u32)k : 0u, nba, scaled_mask);
       if (rc) return rc;
     }
     if (!one_queue) {   // three queues share one workspace: drain before the next slab reuses it
@@ -943,7 +964,7 @@ int run_windows(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u32 n
   rc = run_windows_finish(ctx, wr, wr.d_out, wr.send_bytes(), raw);
   if (rc) return rc;
   const auto th0 = std::chrono::steady_clock::now();
-  sum_slab_records<P64, G>(ctx, raw.data(), wr.out_slab, wr.nslabs, nw, L, host_out, fold);
+  sum_slab_records<P64, G>(ctx, raw.data(), wr.out_slab, wr.nrec, nw, L, host_out, fold);
   ctx->host_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
   return LEMSM_OK;
 }
@@ -997,7 +1018,7 @@ int msm_batch_t(lemsm_ctx* ctx, int curve, const void* const* d_scalars, const v
     int rc = run_windows_finish(c, wr[k & 1], wr[k & 1].d_out, wr[k & 1].send_bytes(), raw);
     if (rc) { ctx->last_error = c->last_error; ctx->bad_index = c->bad_index; return rc; }
     std::vector<host::pt> sums;
-    sum_slab_records<P64, G>(ctx, raw.data(), wr[k & 1].out_slab, wr[k & 1].nslabs, mp.W, mp.L, sums, true);
+    sum_slab_records<P64, G>(ctx, raw.data(), wr[k & 1].out_slab, wr[k & 1].nrec, mp.W, mp.L, sums, true);
     msm_combine_t<P64>(mp, sums.data(), outs + 12 * k);
     return LEMSM_OK;
   };
@@ -1219,7 +1240,7 @@ int sharded_records(lemsm_ctx* ctx, MakeSrc make_src, size_t n, u32 c, u32 nb, u
   for (int r = 0; r < ex.world; r++) {
     u32 a, b; shard_range(W, ex.world, r, a, b);
     if (a == b) continue;
-    sum_slab_records<P64, G>(ctx, raw.data() + (size_t)r * sb, wr.out_slab, wr.nslabs, b - a, L, part);
+    sum_slab_records<P64, G>(ctx, raw.data() + (size_t)r * sb, wr.out_slab, wr.nrec, b - a, L, part);
     std::copy(part.begin(), part.end(), all.begin() + (size_t)a * (L + 1));
   }
   return LEMSM_OK;
@@ -1580,6 +1601,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "dw_kb")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_kb = value; }
   else if (!strcmp(name, "dw_fuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_fuse = value; }
   else if (!strcmp(name, "dw_pw_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_pw_lazy = value; }
+  else if (!strcmp(name, "slab_tail")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_tail = value; }
   else if (!strcmp(name, "dw_halves")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_halves = value; }
   else if (!strcmp(name, "dw_ntt_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_ntt_lazy = value; }
   else if (!strcmp(name, "dw_reuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_reuse = value; }

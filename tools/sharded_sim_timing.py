@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-GPU rehearsal of the C ABI's sharded MSM entry (lemsm_debug_msm_sharded_sim): the G ranks' pipelines of one
 2^LOGN MSM run one after the other; prints wall time per call and per rank, and the device time per rank.
-usage: sharded_sim_timing.py [LOGN] [G...]"""
+usage: [SIM_OPTIONS=name=value,...] sharded_sim_timing.py [LOGN] [G...]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -11,6 +11,8 @@ logn = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 Gs = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
 n = 1 << logn
 ctx = Context(0)
+for kv in filter(None, os.environ.get("SIM_OPTIONS", "").split(",")):      # e.g. SIM_OPTIONS=slab_tail=2
+    k, v = kv.split("="); ctx.set_option(k, int(v))
 sc = gen_scalars(n, ORDER["bn254_g1"], 5)
 q = np.zeros(8, np.uint64); fp = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 q[:4] = np.frombuffer(((1 << 256) % fp).to_bytes(32, "little"), np.uint64); q[4:] = np.frombuffer(((2 << 256) % fp).to_bytes(32, "little"), np.uint64)
