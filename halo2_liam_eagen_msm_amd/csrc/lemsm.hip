@@ -2134,17 +2134,38 @@ int lemsm_node_set_bases(lemsm_node* nd, int curve, const uint64_t* points_affin
   return LEMSM_OK;
 }
 
+// Staging of a call's scalars on every GPU, in two steps so that no rank can be left waiting in a collective:
+// node_reserve_scalars (no collective: allocation only) and node_stage_scalars.  Every GPU uploads ONE G-th of the vector
+// over its own PCIe link and an in-place ncclAllGather over xGMI completes the copies: the host's memory is read once, not
+// G times (r02 uploaded the whole vector to every GPU from pageable memory).  The chunk is a whole number of scalars; the
+// buffers hold G chunks (>= n scalars; what lies beyond n is never read).
+static size_t node_chunk_scalars(const lemsm_node* nd, size_t n) { const size_t G = nd->ctx.size(); return (n + G - 1) / G; }
+static int node_reserve_scalars(lemsm_node* nd, int i, size_t n) {
+  lemsm_ctx* c = nd->ctx[i];
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t need = node_chunk_scalars(nd, n) * nd->ctx.size() * 32 + 64;
+  if (nd->cap_s[i] < need) {
+    if (nd->d_scalars[i]) { HIPCHK(c, hipFree(nd->d_scalars[i])); nd->d_scalars[i] = nullptr; nd->cap_s[i] = 0; }
+    hipError_t e = hipMalloc(&nd->d_scalars[i], need);
+    if (e != hipSuccess) return fail(c, LEMSM_ERR_NOMEM, hipGetErrorString(e));
+    nd->cap_s[i] = need;
+  }
+  return LEMSM_OK;
+}
 static int node_stage_scalars(lemsm_node* nd, int i, const uint8_t* scalars, size_t n) {
   lemsm_ctx* c = nd->ctx[i];
   HIPCHK(c, hipSetDevice(c->device));
-  if (nd->cap_s[i] < n * 32) {
-    if (nd->d_scalars[i]) { HIPCHK(c, hipFree(nd->d_scalars[i])); nd->d_scalars[i] = nullptr; nd->cap_s[i] = 0; }
-    hipError_t e = hipMalloc(&nd->d_scalars[i], n * 32 + 64);
-    if (e != hipSuccess) return fail(c, LEMSM_ERR_NOMEM, hipGetErrorString(e));
-    nd->cap_s[i] = n * 32 + 64;
-  }
-  if (n) HIPCHK(c, hipMemcpy(nd->d_scalars[i], scalars, n * 32, hipMemcpyHostToDevice));
-  return LEMSM_OK;
+  const size_t G = nd->ctx.size(), chunk = node_chunk_scalars(nd, n);
+  if (n == 0) return LEMSM_OK;
+  const size_t lo = std::min(n, (size_t)i * chunk), hi = std::min(n, lo + chunk);
+  char* mine = (char*)nd->d_scalars[i] + (size_t)i * chunk * 32;
+  hipError_t e = hi > lo ? hipMemcpy(mine, scalars + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice) : hipSuccess;
+  if (G == 1) { if (e != hipSuccess) return fail(c, LEMSM_ERR_HIP, hipGetErrorString(e)); return LEMSM_OK; }
+  if (e != hipSuccess) { (void)fail(c, LEMSM_ERR_HIP, hipGetErrorString(e)); comm_abort(c); return LEMSM_ERR_HIP; }   // peers are (about to be) in the all-gather
+  if (!c->comm) return fail(c, LEMSM_ERR_RCCL, "node: no communicator");
+  ncclResult_t r_ = Rccl::get().AllGather(mine, nd->d_scalars[i], chunk * 32, ncclUint8, c->comm, c->stream);   // in place: send = recv + rank * count
+  if (r_ != ncclSuccess) { c->last_error = std::string("ncclAllGather (scalars): ") + Rccl::get().GetErrorString(r_); comm_abort(c); return LEMSM_ERR_RCCL; }
+  return LEMSM_OK;                                 // (the MSM that follows is enqueued on the same queue: stream order)
 }
 
 // best_multiexp over the node: scalars (host) are replicated to every GPU, each GPU accumulates its Pippenger windows,
@@ -2154,8 +2175,10 @@ int lemsm_node_msm(lemsm_node* nd, const uint8_t* scalars, size_t n, uint64_t ou
   if (nd->curve < 0) { nd->last_error = "lemsm_node_set_bases first"; return LEMSM_ERR_BAD_ARG; }
   if (n > nd->n_bases) { nd->last_error = "more scalars than resident bases"; return LEMSM_ERR_LEN_MISMATCH; }
   std::vector<uint64_t> outs((size_t)nd->ctx.size() * 12);
-  // phase 1, no collective: every GPU stages the scalars; any failure ends the call before a rank could be left waiting
-  int rc = node_parallel(nd, [&](int i) -> int { return node_stage_scalars(nd, i, scalars, n); });
+  // phase 1: buffers first (no collective: a failed allocation ends the call before any rank waits), then the staging
+  int rc = node_parallel(nd, [&](int i) -> int { return node_reserve_scalars(nd, i, n); });
+  if (rc) return rc;
+  rc = node_parallel(nd, [&](int i) -> int { return node_stage_scalars(nd, i, scalars, n); });
   if (rc) return rc;
   // phase 2: the collective call (itself collective-safe: sharded_records)
   rc = node_parallel(nd, [&](int i) -> int {
@@ -2176,7 +2199,9 @@ int lemsm_node_lhs_msm(lemsm_node* nd, const uint8_t* scalars, size_t n, uint8_t
   const size_t G = nd->ctx.size();
   std::vector<uint64_t> carry(G * 12), carries(out_carries ? G * 12 * d : 0);
   std::vector<size_t> bad(G, 0);
-  rc = node_parallel(nd, [&](int i) -> int { return node_stage_scalars(nd, i, scalars, n); });   // phase 1, no collective
+  rc = node_parallel(nd, [&](int i) -> int { return node_reserve_scalars(nd, i, n); });          // phase 1, no collective
+  if (rc) return rc;
+  rc = node_parallel(nd, [&](int i) -> int { return node_stage_scalars(nd, i, scalars, n); });   // one G-th each over PCIe, all-gather over xGMI
   if (rc) return rc;
   rc = node_parallel(nd, [&](int i) -> int {
     return lemsm_lhs_msm_sharded_device(nd->ctx[i], nd->curve, nd->d_scalars[i], nd->d_points[i], n, base, carry.data() + 12 * (size_t)i,
