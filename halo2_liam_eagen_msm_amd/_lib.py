@@ -52,7 +52,7 @@ SYMBOLS = [
     "lemsm_msm_sharded_device", "lemsm_lhs_msm_sharded_device",
     "lemsm_node_create", "lemsm_node_destroy", "lemsm_node_size", "lemsm_node_ctx", "lemsm_node_last_error",
     "lemsm_node_set_bases", "lemsm_node_msm", "lemsm_node_lhs_msm",
-    "lemsm_bases_upload", "lemsm_bases_free", "lemsm_bases_device_ptr", "lemsm_msm_with_bases",
+    "lemsm_bases_upload", "lemsm_bases_free", "lemsm_bases_device_ptr", "lemsm_msm_with_bases", "lemsm_msm_batch_with_bases",
     "lemsm_debug_msm_sharded_sim", "lemsm_debug_lhs_sharded_sim",
     "lemsm_prepare_scalar_witness_batch", "lemsm_table_entries",
     "lemsm_divisor_witness", "lemsm_divisor_witness_device", "lemsm_divisor_witness_batch", "lemsm_divisor_last_ntt", "lemsm_lhs_witness", "lemsm_lhs_witness_device", "lemsm_lhs_witness_device_range", "lemsm_lhs_witness_last_phases", "lemsm_debug_ntt",
@@ -146,6 +146,7 @@ def load() -> ctypes.CDLL:
         "lemsm_bases_free": (None, [vp]),
         "lemsm_bases_device_ptr": (vp, [vp]),
         "lemsm_msm_with_bases": (i, [vp, vp, u8p, sz, u64p]),
+        "lemsm_msm_batch_with_bases": (i, [vp, vp, vp, sz, sz, u64p]),
         "lemsm_debug_msm_sharded_sim": (i, [vp, i, vp, vp, sz, i, u64p]),
         "lemsm_debug_lhs_sharded_sim": (i, [vp, i, vp, vp, sz, ctypes.c_uint8, i, u64p, u64p, szp]),
         "lemsm_prepare_scalar_witness_batch": (i, [vp, u8p, u8p, sz, ctypes.c_uint8, ctypes.c_uint32, ctypes.c_uint32, u8p, szp]),

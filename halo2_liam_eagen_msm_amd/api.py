@@ -335,6 +335,19 @@ class Context:
         self._check(self.lib.lemsm_msm_with_bases(self.h, bases.h, _ptr(s), s.shape[0], _ptr(out)))
         return out
 
+    def msm_batch_with_bases(self, bases: "Bases", scalars_list) -> np.ndarray:
+        """len(scalars_list) MSMs over the same resident bases, scalar vectors in host memory, uploads pipelined with the
+        compute inside the library (lemsm_msm_batch_with_bases); returns (K, 12) Jacobian results"""
+        ss = [_scalars(x) for x in scalars_list]
+        K = len(ss)
+        n = ss[0].shape[0] if K else 0
+        if any(x.shape[0] != n for x in ss):
+            raise ValueError("all scalar vectors of a batch have the same length")
+        out = np.zeros((max(K, 1), 12), np.uint64)
+        ptrs = (ctypes.c_void_p * max(K, 1))(*[x.ctypes.data for x in ss])
+        self._check(self.lib.lemsm_msm_batch_with_bases(self.h, bases.h, ptrs, K, n, _ptr(out)))
+        return out[:K]
+
     # ---- negabase ------------------------------------------------------------------
     def negbase_decompose_batch(self, scalars, base: int, d: int) -> np.ndarray:
         s = _scalars(scalars)

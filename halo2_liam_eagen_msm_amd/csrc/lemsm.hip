@@ -91,6 +91,9 @@ struct lemsm_ctx {
   hipStream_t stream_sort = nullptr;   // digit + sort passes of the next window group (high priority)
   hipStream_t stream_tail = nullptr;   // edge-record levels + pyramid of the previous group
   std::vector<hipEvent_t> evpool;
+  hipEvent_t wait_accum = nullptr;               // batch entries: the other lane's accumulation must have ended before this call's starts (run_group)
+  hipEvent_t ev_call_done = nullptr;             // batch entries: everything this lane enqueued for its call has run
+  hipEvent_t ev_batch_up = nullptr;              // lemsm_msm_batch_with_bases: this lane's scalars have arrived
   hipEvent_t dw_ev[2] = {nullptr, nullptr};      // divisor witness: the two half-level pointwise chains (divisor_abi.inc)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [4]: the digit pass's error words have reached the host
   DevBuf ws;        // workspace arena
@@ -551,6 +554,9 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   st = s_acc;
   HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_sorted, 0));
   if (ev_points) HIPCHK(ctx, hipStreamWaitEvent(s_acc, ev_points, 0));
+  // batch entries: two accumulations side by side run ~25 % slower than one after the other (measured: 2 x 2^24 in 49 ms
+  // against 2 x 19.3), so this call's waits for the other lane's; its digit and sort passes above did not
+  if (ctx->wait_accum) HIPCHK(ctx, hipStreamWaitEvent(s_acc, ctx->wait_accum, 0));
   HIPCHK(ctx, hipEventRecord(ev_acc0, s_acc));
   {
     dim3 grid((pl.nthr1 + 255) / 256), blk(256);
@@ -999,18 +1005,44 @@ int msm_partial_t(lemsm_ctx* ctx, int curve, const void* d_scalars, const void* 
 // pyramid: a few dozen dependent launches that occupy a fraction of the chip) runs beside call k's digit / sort passes
 // and fills the wave slots its accumulation leaves.  Matches how a prover uses best_multiexp: many calls, one SRS.
 template <class P64, class G>
-int msm_batch_t(lemsm_ctx* ctx, int curve, const void* const* d_scalars, const void* d_points, size_t n, size_t K, u64* outs) {
+int msm_batch_t(lemsm_ctx* ctx, int curve, const void* const* d_scalars, const void* d_points, size_t n, size_t K, u64* outs,
+                const uint8_t* const* h_scalars = nullptr /* scalars in host memory instead (lemsm_msm_batch_with_bases): call k's are uploaded
+                into its lane's staging buffer on the lane's second queue while the GPU still works on call k - 1 */) {
   lemsm_ctx* lane[2] = {ctx, ctx->peer};
   MsmPlan mp = make_msm_plan(ctx, curve, n);
   WinRun wr[2];
   auto enqueue = [&](size_t k) -> int {
     lemsm_ctx* c = lane[k & 1];
-    const void* sc = d_scalars[k];
+    const void* sc = h_scalars ? nullptr : d_scalars[k];
+    if (h_scalars) {
+      int rcr = reserve(c, c->in_s, n * 32); if (rcr) return rcr;      // (the lane's call k - 2 has been finished: the buffer is free)
+      if (!c->ev_batch_up) HIPCHK(c, hipEventCreateWithFlags(&c->ev_batch_up, hipEventDisableTiming));
+      HIPCHK(c, hipMemcpyAsync(c->in_s.p, h_scalars[k], n * 32, hipMemcpyHostToDevice, c->stream_sort));
+      HIPCHK(c, hipEventRecord(c->ev_batch_up, c->stream_sort));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_batch_up, 0));
+      sc = c->in_s.p;
+    }
     auto make_src = [&](size_t s0, u32) {
       PipProvider s; s.scalars = (const uint4*)((const char*)sc + s0 * 32);
       memcpy(s.kadd.k, mp.kadd, 32); memcpy(s.kadd.order, order_of(curve), 32); return s;
     };
-    return run_windows_enqueue<P64, G>(c, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, 0, mp.W, 0, d_points, mp.W, wr[k & 1]);
+    c->wait_accum = nullptr;
+    if (k > 0) {
+      lemsm_ctx* o = lane[(k - 1) & 1]; const WinRun& w = wr[(k - 1) & 1];
+      // resident scalars: wait for the END OF THE ACCUMULATION of the call before (other lane), so that its tail runs beside this
+      // call's accumulation.  Host scalars: wait for the whole call -- under a full-chip accumulation the tail's few dozen
+      // dependent launches starve (measured: call k - 1 completed together with call k, and the host, waiting for it, could not
+      // start the next upload: 24.5 ms per 2^24 MSM instead of the 19 the GPU needs)
+      if (h_scalars) c->wait_accum = o->ev_call_done;
+      else if (w.ng && w.nslabs && o->evpool.size() >= 3 * w.ng * w.nslabs) c->wait_accum = o->evpool[3 * (w.ng * w.nslabs - 1) + 2];
+    }
+    int rce = run_windows_enqueue<P64, G>(c, make_src, n, mp.c, mp.nb, mp.nbp, mp.L, mp.W, 0, mp.W, 0, d_points, mp.W, wr[k & 1]);
+    c->wait_accum = nullptr;
+    if (!rce && h_scalars) {
+      if (!c->ev_call_done) HIPCHK(c, hipEventCreateWithFlags(&c->ev_call_done, hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->ev_call_done, records_stream(c)));
+    }
+    return rce;
   };
   auto finish = [&](size_t k) -> int {
     lemsm_ctx* c = lane[k & 1];
@@ -1023,11 +1055,17 @@ int msm_batch_t(lemsm_ctx* ctx, int curve, const void* const* d_scalars, const v
     return LEMSM_OK;
   };
   int rc = LEMSM_OK; size_t enq = 0;
+  const bool stamps = getenv("LEMSM_DEBUG_STAMPS") != nullptr;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tb = now_us();
   for (size_t k = 0; k < K && !rc; k++) {
+    const double t0 = now_us();
     rc = enqueue(k);
+    const double t1 = now_us();
     if (rc) { if (lane[k & 1] != ctx) ctx->last_error = lane[k & 1]->last_error; break; }
     enq = k + 1;
     if (k > 0) rc = finish(k - 1);
+    if (stamps) fprintf(stderr, "[lemsm batch] call %zu: enqueue (upload + launches) %.0f us at %.0f, finish of the call before %.0f us\n", k, t1 - t0, t0 - tb, now_us() - t1);
   }
   if (!rc && enq == K && K) rc = finish(K - 1);
   if (rc) for (lemsm_ctx* c : lane) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }   // nothing of this call may still run when it returns
@@ -1577,6 +1615,8 @@ void lemsm_destroy(lemsm_ctx* ctx) {
   for (auto& kv : ctx->pyr_cache) if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
   for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   for (int i = 0; i < 2; i++) if (ctx->dw_ev[i]) (void)hipEventDestroy(ctx->dw_ev[i]);
+  if (ctx->ev_batch_up) (void)hipEventDestroy(ctx->ev_batch_up);
+  if (ctx->ev_call_done) (void)hipEventDestroy(ctx->ev_call_done);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1693,16 +1733,21 @@ int lemsm_msm_device(lemsm_ctx* ctx, int curve, const void* d_scalars, const voi
   return LEMSM_OK;
 }
 
-int lemsm_msm_batch_device(lemsm_ctx* ctx, int curve, const void* const* d_scalars, size_t batch, const void* d_points, size_t n, uint64_t* outs) {
-  if (!ctx || (batch && (!d_scalars || !outs))) return LEMSM_ERR_BAD_ARG;
+struct lemsm_bases { lemsm_ctx* ctx; int device; int curve; size_t n; void* d_points; bool validated; };   // `device` kept here: the context may be gone when the bases are freed
+// common part of lemsm_msm_batch_device (scalars resident: d_scalars) and lemsm_msm_batch_with_bases (scalars in host memory: h_scalars)
+static int msm_batch_entry(lemsm_ctx* ctx, int curve, const void* const* d_scalars, const uint8_t* const* h_scalars, const lemsm_bases* bases,
+                           size_t batch, const void* d_points, size_t n, uint64_t* outs) {
   int rc = check_curve(ctx, curve); if (rc) return rc;
   if (batch == 0) return LEMSM_OK;
   if (n == 0) { memset(outs, 0, batch * 96); return LEMSM_OK; }
-  for (size_t k = 0; k < batch; k++) if (!d_scalars[k]) return LEMSM_ERR_BAD_ARG;
+  for (size_t k = 0; k < batch; k++) if (h_scalars ? !h_scalars[k] : !d_scalars[k]) return LEMSM_ERR_BAD_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  rc = validate_points(ctx, curve, d_points, n); if (rc) return rc;
+  if (!(bases && bases->validated)) { rc = validate_points(ctx, curve, d_points, n); if (rc) return rc; }
   if (ctx->opt_field == 1 || ctx->opt_groups > 1 || batch == 1) {       // A/B arithmetic, pipelined window groups, or nothing to overlap: one call after the other
-    for (size_t k = 0; k < batch; k++) { rc = lemsm_msm_device(ctx, curve, d_scalars[k], d_points, n, outs + 12 * k); if (rc) return rc; }
+    for (size_t k = 0; k < batch; k++) {
+      rc = h_scalars ? lemsm_msm_with_bases(ctx, bases, h_scalars[k], n, outs + 12 * k) : lemsm_msm_device(ctx, curve, d_scalars[k], d_points, n, outs + 12 * k);
+      if (rc) return rc;
+    }
     return LEMSM_OK;
   }
   if (!ctx->peer) { rc = lemsm_create(ctx->device, &ctx->peer); if (rc) return fail(ctx, rc, "lemsm_msm_batch_device: second lane could not be created"); }
@@ -1712,10 +1757,15 @@ int lemsm_msm_batch_device(lemsm_ctx* ctx, int curve, const void* const* d_scala
     p->opt_accum_waves = ctx->opt_accum_waves; p->opt_groups = ctx->opt_groups; p->opt_slab_bits = ctx->opt_slab_bits; p->opt_abi_points = ctx->opt_abi_points;
     p->opt_stage2x = ctx->opt_stage2x; p->opt_xcd_windows = ctx->opt_xcd_windows; p->opt_entry_ring = ctx->opt_entry_ring; p->opt_pyr_fuse = ctx->opt_pyr_fuse;
     p->opt_ws_canary = ctx->opt_ws_canary; p->opt_binsort = ctx->opt_binsort; p->opt_merge_slice = ctx->opt_merge_slice; p->opt_merge_wave_th = ctx->opt_merge_wave_th;
-    p->opt_pyr_first2 = ctx->opt_pyr_first2; p->opt_host_threads = ctx->opt_host_threads; p->plan_world = ctx->plan_world;
+    p->opt_pyr_first2 = ctx->opt_pyr_first2; p->opt_host_threads = ctx->opt_host_threads; p->plan_world = ctx->plan_world; p->opt_slab_tail = ctx->opt_slab_tail;
   }
-  if (curve == LEMSM_BN254_G1) return msm_batch_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, batch, outs);
-  return msm_batch_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, batch, outs);
+  if (curve == LEMSM_BN254_G1) return msm_batch_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, batch, outs, h_scalars);
+  return msm_batch_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, batch, outs, h_scalars);
+}
+
+int lemsm_msm_batch_device(lemsm_ctx* ctx, int curve, const void* const* d_scalars, size_t batch, const void* d_points, size_t n, uint64_t* outs) {
+  if (!ctx || (batch && (!d_scalars || !outs))) return LEMSM_ERR_BAD_ARG;
+  return msm_batch_entry(ctx, curve, d_scalars, nullptr, nullptr, batch, d_points, n, outs);
 }
 
 int lemsm_msm(lemsm_ctx* ctx, int curve, const uint8_t* scalars, const uint64_t* points, size_t n, uint64_t out[12]) {
@@ -2009,7 +2059,6 @@ int lemsm_debug_lhs_sharded_sim(lemsm_ctx* ctx, int curve, const void* d_scalars
 }
 
 // ---- resident bases (halo2's bases are a fixed SRS: upload once, then only scalars cross PCIe) ------------------
-struct lemsm_bases { lemsm_ctx* ctx; int device; int curve; size_t n; void* d_points; bool validated; };   // `device` kept here: the context may be gone when the bases are freed
 
 int lemsm_bases_upload(lemsm_ctx* ctx, int curve, const uint64_t* points_affine, size_t n, lemsm_bases** out) {
   if (!ctx || !out || (n && !points_affine)) return LEMSM_ERR_BAD_ARG;
@@ -2049,6 +2098,15 @@ int lemsm_msm_with_bases(lemsm_ctx* ctx, const lemsm_bases* bases, const uint8_t
   ctx->opt_validate_points = saved_validate;
   ctx->host_stage = nullptr;
   return rc;
+}
+
+// `batch` MSMs over the same resident bases, scalars in host memory: the upload of call k's scalars (its lane's second queue)
+// and the host fold of call k - 1 run while the GPU accumulates call k - 1 / k; per call the longer of the two, not their sum.
+int lemsm_msm_batch_with_bases(lemsm_ctx* ctx, const lemsm_bases* bases, const uint8_t* const* scalars, size_t batch, size_t n, uint64_t* outs) {
+  if (!ctx || !bases || (batch && (!scalars || !outs))) return LEMSM_ERR_BAD_ARG;
+  if (bases->ctx != ctx) return fail(ctx, LEMSM_ERR_BAD_ARG, "bases belong to another context");
+  if (n > bases->n) return fail(ctx, LEMSM_ERR_LEN_MISMATCH, "more scalars than resident bases");
+  return msm_batch_entry(ctx, bases->curve, nullptr, scalars, bases, batch, bases->d_points, n, outs);
 }
 
 // ---- one process, all GPUs of the node: what a Rust host binds -----------------------------

@@ -207,6 +207,12 @@ int lemsm_bases_upload(lemsm_ctx* ctx, int curve, const uint64_t* points_affine,
 void lemsm_bases_free(lemsm_bases* bases);
 const void* lemsm_bases_device_ptr(const lemsm_bases* bases);
 int lemsm_msm_with_bases(lemsm_ctx* ctx, const lemsm_bases* bases, const uint8_t* scalars, size_t n, uint64_t out_jacobian[12]);
+/* `batch` MSMs over the same resident bases with the scalar vectors in host memory (scalars[k]: n x 32 B; outs: batch x 12 limbs):
+   the upload of call k's scalars and the host fold of call k - 1 run while the GPU works on the neighbouring call, so a call costs
+   the longer of upload and compute, not their sum (how a prover calls best_multiexp over one SRS:
+   /root/reference/src/argument_witness_calc.rs:144).  Results equal `batch` lemsm_msm_with_bases calls; the first failing
+   call's status is returned. */
+int lemsm_msm_batch_with_bases(lemsm_ctx* ctx, const lemsm_bases* bases, const uint8_t* const* scalars, size_t batch, size_t n, uint64_t* outs);
 
 /* ---- negabase decomposition ---------------------------------------------------------- */
 int lemsm_num_digits(int curve, uint8_t base, uint32_t* d);

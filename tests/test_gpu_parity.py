@@ -327,6 +327,35 @@ def test_msm_batch_equals_separate_calls(ctx, curve):
         assert canon(curve, again[k]) == canon(curve, got[k])
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm_batch_with_bases_host_scalars(ctx, curve):
+    """lemsm_msm_batch_with_bases: K MSMs over resident bases with the scalar vectors in host memory (uploads pipelined with the
+    compute): the results of K lemsm_msm_with_bases calls; shorter than the bases; a bad scalar fails the batch with its index"""
+    n = 9000
+    pts = cref.gen_points(curve.cid, 970, n)
+    bases = ctx.bases_upload(curve.cid, pts)
+    scs = [cref.gen_scalars(curve.cid, 980 + k, n) for k in range(5)]
+    got = ctx.msm_batch_with_bases(bases, scs)
+    assert got.shape == (5, 12)
+    for k in range(5):
+        assert canon(curve, got[k]) == canon(curve, cref.best_multiexp(curve.cid, scs[k], pts, 8)), k
+        assert canon(curve, got[k]) == canon(curve, ctx.msm_with_bases(bases, scs[k])), k
+    m = 6001
+    short = ctx.msm_batch_with_bases(bases, [s[:m] for s in scs[:3]])
+    for k in range(3):
+        assert canon(curve, short[k]) == canon(curve, cref.best_multiexp(curve.cid, scs[k][:m], pts[:m], 8)), k
+    assert ctx.msm_batch_with_bases(bases, []).shape[0] == 0
+    one = ctx.msm_batch_with_bases(bases, [scs[2]])
+    assert canon(curve, one[0]) == canon(curve, got[2])
+    bad = scs[3].copy(); bad[1234] = 0xff
+    with pytest.raises(api.ScalarOutOfRange) as e:
+        ctx.msm_batch_with_bases(bases, [scs[0], bad, scs[4]])
+    assert e.value.index == 1234
+    again = ctx.msm_batch_with_bases(bases, scs[:2])
+    for k in range(2):
+        assert canon(curve, again[k]) == canon(curve, got[k])
+
+
 def test_msm_all_zero_scalars_and_all_identity_points(fctx):
     ctx = fctx
     curve = pyref.GRUMPKIN

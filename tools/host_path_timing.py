@@ -38,3 +38,16 @@ for bits in (0, 22, 21, 20):
         assert jacobian_to_canonical(0, out) == ref
         best = min(best, dt)
     print("2^%d host_slab_bits=%d: lemsm_msm_with_bases (scalars from host, bases resident) %.1f ms (%.0f Mpairs/s)" % (logn, bits, best * 1e3, n / best / 1e6), flush=True)
+
+# the same as a batch: K scalar vectors from host memory, call k's upload beside call k - 1's compute (lemsm_msm_batch_with_bases)
+ctx.set_option("host_slab_bits", 0)
+distinct = [sc] + [gen_scalars(n, ORDER["bn254_g1"], 100 + k) for k in range(1, 3)]
+for K in (4, 12):
+    scs = [distinct[k % 3] for k in range(K)]
+    best = 1e9
+    for it in range(3):
+        t0 = time.perf_counter(); outs = ctx.msm_batch_with_bases(bases, scs); dt = time.perf_counter() - t0
+        assert jacobian_to_canonical(0, outs[0]) == ref and jacobian_to_canonical(0, outs[3]) == ref
+        best = min(best, dt)
+    print("2^%d lemsm_msm_batch_with_bases, K = %d scalar vectors from (pageable) host memory: %.1f ms per call = %.1f ms per MSM (%.0f Mpairs/s)"
+          % (logn, K, best * 1e3, best * 1e3 / K, n * K / best / 1e6), flush=True)
