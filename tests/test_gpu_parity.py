@@ -427,15 +427,15 @@ def test_msm_device_entry_multi_slab(fctx, groups):
         ctx.set_option("slab_bits", 0); ctx.set_option("groups", 0)
 
 
-@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("n,slab_bits,abi_points", [(2 * 4096 + 1, 12, 0), (7 * 4096 + 4095, 12, 0), (8 * 4096, 12, 2), (9 * 4096 + 7, 12, 0), (3 * 65536 + 100, 16, 0), (65536 + 64, 16, 1)])
-def test_msm_slabs_share_one_tail(fctx, curve, n, slab_bits, abi_points):
+@pytest.mark.parametrize("n,slab_bits,abi_points", [(2 * 4096 + 1, 12, 0), (3 * 4096 + 4095, 12, 2), (8 * 4096, 12, 0), (9 * 4096 + 7, 12, 0)])
+def test_msm_slabs_share_one_tail(fctx, n, slab_bits, abi_points):
     """several slabs per call: by default every slab accumulates into its own bucket area and the call runs ONE bucket
     reduction (k_sum_slabs + one pyramid, one block of records); option slab_tail = 2 runs a reduction per slab and adds
     the records on the host.  Both equal the oracle; sizes: a one-point ragged last slab (its accumulate form differs from
-    the full slabs'), exactly 8 slabs, 10 slabs (above the limit: a tail per slab either way), 64 Ki-point slabs; also
-    through the sharded entry, whose exchange carries one record block per rank"""
+    the full slabs'), exactly 8 slabs, 10 slabs (above the limit: a tail per slab either way); also through the sharded
+    entry, whose exchange carries one record block per rank.  (64 Ki-point slabs: test_msm_slabs_share_one_tail_64k.)"""
     ctx = fctx
+    curve = pyref.BN254_G1                                          # (Grumpkin: test_msm_slabs_share_one_tail_64k)
     pts = cref.gen_points(curve.cid, 4100 + n % 97, n); sc = cref.gen_scalars(curve.cid, 4200 + n % 89, n)
     if n > 3 * 4096:
         sc[4096:4096 + 300] = sc[7]; pts[4096 + 5] = 0            # a long bucket and an identity inside the second slab
@@ -449,6 +449,24 @@ def test_msm_slabs_share_one_tail(fctx, curve, n, slab_bits, abi_points):
             assert canon(curve, ctx.debug_msm_sharded_sim(curve.cid, ds.ptr, dp.ptr, n, 3)) == exp, mode
     finally:
         ctx.set_option("slab_bits", 0); ctx.set_option("abi_points", 0); ctx.set_option("slab_tail", 0)
+    ds.free(); dp.free()
+
+
+def test_msm_slabs_share_one_tail_64k(ctx):
+    """the same with 64 Ki-point slabs (three and a ragged bit), default arithmetic, one curve: the slab size at which the sort
+    takes its full-size path (4096-entry ranges, k_binsort)"""
+    curve = pyref.GRUMPKIN
+    n = 2 * 65536 + 100
+    pts = cref.gen_points(curve.cid, 4301, n); sc = cref.gen_scalars(curve.cid, 4302, n)
+    exp = canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    ds, dp = ctx.to_device(sc), ctx.to_device(pts)
+    ctx.set_option("slab_bits", 16)
+    try:
+        for mode in (0, 2):
+            ctx.set_option("slab_tail", mode)
+            assert canon(curve, ctx.msm_device(curve.cid, ds.ptr, dp.ptr, n)) == exp, mode
+    finally:
+        ctx.set_option("slab_bits", 0); ctx.set_option("slab_tail", 0)
     ds.free(); dp.free()
 
 
