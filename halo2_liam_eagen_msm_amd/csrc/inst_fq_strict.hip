@@ -8,6 +8,6 @@ template __global__ void lemsm::k_merge_pairs<G>(GroupPlan, u32, MqLayout, const
 template __global__ void lemsm::k_merge_serial<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*);
 template __global__ void lemsm::k_merge_waves<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*, char*, u32*);
 template __global__ void lemsm::k_merge_final<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*, u32*);
-template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*);
+template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*, u32);
 template __global__ void lemsm::k_pyramid_first2<G>(PyrFirst2Args, const u32*, char*, u32*);
-template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*);
+template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*, u32);

@@ -362,10 +362,23 @@ __device__ __forceinline__ void pyr_item(const PyrTask& tk, u32 w, u32 i, char* 
   G::store(arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride + i) * G::PT_BYTES, a);
 }
 
+// the same with four lanes per item where the arithmetic has that form (XYZZ29::add4_mem): true if the quad has stored the sum
+template <class G>
+__device__ __forceinline__ bool pyr_try4(const PyrTask& tk, u32 w, u32 i, char* __restrict__ arena, u32 q) {
+  if constexpr (G::CONVERTED_DOMAIN) {
+    const u32 ia = (2 * i) * tk.stride + tk.phase, ib = (2 * i + 1) * tk.stride + tk.phase;
+    if (ia >= tk.src_valid || ib >= tk.src_valid || tk.src_scaled) return false;
+    const char* src = arena + ((size_t)tk.src_off + (size_t)w * tk.src_wstride) * G::PT_BYTES;
+    return G::add4_mem(src + (size_t)ia * G::PT_BYTES, src + (size_t)ib * G::PT_BYTES,
+                       arena + ((size_t)tk.dst_off + (size_t)w * tk.dst_wstride + i) * G::PT_BYTES, q);
+  } else return false;
+}
+
 template <class G>
 __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tasks, u32 ntasks, u32 nwin,
-                                                 u32 max_count, char* __restrict__ arena) {
-  u32 gid = blockIdx.x * 256 + threadIdx.x;
+                                                 u32 max_count, char* __restrict__ arena, u32 quad /* four lanes per item (a narrow step) */) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  const u32 gid = quad ? t >> 2 : t;
   u32 per_task = max_count * nwin;
   u32 ti = gid / per_task;
   if (ti >= ntasks) return;
@@ -373,7 +386,9 @@ __global__ __launch_bounds__(256) void k_pyramid(const PyrTask* __restrict__ tas
   u32 w = rem / max_count, i = rem - w * max_count;
   PyrTask tk = tasks[ti];
   if (i >= tk.count) return;
-  pyr_item<G>(tk, w, i, arena);
+  bool serial = true;
+  if (quad) serial = !pyr_try4<G>(tk, w, i, arena, t & 3u) && (t & 3u) == 0u;
+  if (serial) pyr_item<G>(tk, w, i, arena);
 }
 
 // One tail per call: with several slabs of points every slab sorts and accumulates into a bucket area of its own (the
@@ -518,16 +533,20 @@ __global__ __launch_bounds__(256, 1) void k_pyramid_first2(PyrFirst2Args a, cons
 // steps: [first, last]; task t of step s is tasks[step_off[s - first] + t].
 struct PyrTailArgs { u32 first, last, max_count[20], step_off[21]; };
 template <class G>
-__global__ __launch_bounds__(1024) void k_pyramid_tail(const PyrTask* __restrict__ tasks, PyrTailArgs ta, const CopyTaskPod* __restrict__ copy,
-                                                       u32 do_copy, char* __restrict__ arena) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pyramid_tail(const PyrTask* __restrict__ tasks, PyrTailArgs ta, const CopyTaskPod* __restrict__ copy,
+                                                       u32 do_copy, char* __restrict__ arena, u32 quad /* four lanes per item */) {
   const u32 w = blockIdx.x, tid = threadIdx.x;
   for (u32 s = ta.first; s <= ta.last; s++) {
     const u32 k = s - ta.first;
     const u32 nt = ta.step_off[k + 1] - ta.step_off[k], mc = ta.max_count[k];
-    for (u32 it = tid; it < nt * mc; it += 1024) {
+    const u32 lanes = quad ? 4u * nt * mc : nt * mc;
+    for (u32 t = tid; t < lanes; t += 1024) {
+      const u32 it = quad ? t >> 2 : t;
       const u32 ti = it / mc, i = it - ti * mc;
       PyrTask tk = tasks[ta.step_off[k] + ti];
-      if (i < tk.count) pyr_item<G>(tk, w, i, arena);
+      bool serial = i < tk.count;
+      if (quad && serial) serial = !pyr_try4<G>(tk, w, i, arena, t & 3u) && (t & 3u) == 0u;
+      if (serial) pyr_item<G>(tk, w, i, arena);
     }
     __threadfence_block();
     __syncthreads();

@@ -54,9 +54,9 @@ const u32* bound_of(int curve) { return curve == LEMSM_BN254_G1 ? BOUND_R : BOUN
   extern template __global__ void lemsm::k_merge_serial<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*); \
   extern template __global__ void lemsm::k_merge_waves<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*, char*, u32*); \
   extern template __global__ void lemsm::k_merge_final<G>(u32, MqLayout, const u32*, const uint4*, const char*, char*, u32*); \
-  extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*); \
+  extern template __global__ void lemsm::k_pyramid<G>(const PyrTask*, u32, u32, u32, char*, u32); \
   extern template __global__ void lemsm::k_pyramid_first2<G>(PyrFirst2Args, const u32*, char*, u32*); \
-  extern template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*);
+  extern template __global__ void lemsm::k_pyramid_tail<G>(const PyrTask*, PyrTailArgs, const CopyTaskPod*, u32, char*, u32);
 #define LEMSM_EXTERN_ACC(G, W) \
   extern template __global__ void lemsm::k_accum1<G, W>(GroupPlan, const u32*, const u32*, u32*, const uint4*, char*, u32*, char*);
 LEMSM_EXTERN_G(GqStrict) LEMSM_EXTERN_G(GrStrict) LEMSM_EXTERN_G(GqLazy) LEMSM_EXTERN_G(GrLazy)
@@ -114,7 +114,7 @@ struct lemsm_ctx {
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
   long opt_host_threads = 0;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0, opt_dw_halves = 0, opt_dw_ntt_lazy = 0, opt_slab_tail = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0, opt_dw_halves = 0, opt_dw_ntt_lazy = 0, opt_slab_tail = 0, opt_pyr_quad = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -626,7 +626,10 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       auto& tasks = pp.steps[s - 1];
       u32 maxc = pp.step_max_count[s - 1];
       size_t threads = (size_t)tasks.size() * maxc * gw;
-      hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, d_tasks + toff, (u32)tasks.size(), gw, maxc, w.arena);
+      // a step that leaves most SIMDs without a wave is one addition deep: four lanes per addition (XYZZ29::add4_mem) make it ~2.6x shallower
+      const u32 quad = (G::CONVERTED_DOMAIN && ctx->opt_pyr_quad != 2 && threads <= 32768 && !(s == 1 && abi_pyr)) ? 1u : 0u;
+      if (quad) threads *= 4;
+      hipLaunchKernelGGL((k_pyramid<G>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, d_tasks + toff, (u32)tasks.size(), gw, maxc, w.arena, quad);
       toff += tasks.size();
     }
     const bool need_copy = !(L == 1 && abi_pyr);
@@ -636,7 +639,8 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
       u32 o = (u32)toff;
       for (u32 s = first_fused; s <= L; s++) { ta.step_off[s - first_fused] = o; ta.max_count[s - first_fused] = pp.step_max_count[s - 1]; o += (u32)pp.steps[s - 1].size(); }
       ta.step_off[L - first_fused + 1] = o;
-      hipLaunchKernelGGL((k_pyramid_tail<G>), dim3(gw), dim3(1024), 0, st, (const PyrTask*)d_tasks, ta, (const CopyTaskPod*)d_copy, need_copy ? 1u : 0u, w.arena);
+      hipLaunchKernelGGL((k_pyramid_tail<G>), dim3(gw), dim3(1024), 0, st, (const PyrTask*)d_tasks, ta, (const CopyTaskPod*)d_copy, need_copy ? 1u : 0u, w.arena,
+                         (G::CONVERTED_DOMAIN && ctx->opt_pyr_quad != 2) ? 1u : 0u);
     } else if (need_copy) {
       u32 cthreads = gw * (u32)(ptb / 16);
       hipLaunchKernelGGL(k_copy_points, dim3((cthreads + 63) / 64), dim3(64), 0, st, d_copy, 1u, gw, (u32)ptb, w.arena);
@@ -1641,6 +1645,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "dw_kb")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_kb = value; }
   else if (!strcmp(name, "dw_fuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_fuse = value; }
   else if (!strcmp(name, "dw_pw_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_pw_lazy = value; }
+  else if (!strcmp(name, "pyr_quad")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_quad = value; }
   else if (!strcmp(name, "slab_tail")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_tail = value; }
   else if (!strcmp(name, "dw_halves")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_halves = value; }
   else if (!strcmp(name, "dw_ntt_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_ntt_lazy = value; }
@@ -1757,7 +1762,7 @@ static int msm_batch_entry(lemsm_ctx* ctx, int curve, const void* const* d_scala
     p->opt_accum_waves = ctx->opt_accum_waves; p->opt_groups = ctx->opt_groups; p->opt_slab_bits = ctx->opt_slab_bits; p->opt_abi_points = ctx->opt_abi_points;
     p->opt_stage2x = ctx->opt_stage2x; p->opt_xcd_windows = ctx->opt_xcd_windows; p->opt_entry_ring = ctx->opt_entry_ring; p->opt_pyr_fuse = ctx->opt_pyr_fuse;
     p->opt_ws_canary = ctx->opt_ws_canary; p->opt_binsort = ctx->opt_binsort; p->opt_merge_slice = ctx->opt_merge_slice; p->opt_merge_wave_th = ctx->opt_merge_wave_th;
-    p->opt_pyr_first2 = ctx->opt_pyr_first2; p->opt_host_threads = ctx->opt_host_threads; p->plan_world = ctx->plan_world; p->opt_slab_tail = ctx->opt_slab_tail;
+    p->opt_pyr_first2 = ctx->opt_pyr_first2; p->opt_host_threads = ctx->opt_host_threads; p->plan_world = ctx->plan_world; p->opt_slab_tail = ctx->opt_slab_tail; p->opt_pyr_quad = ctx->opt_pyr_quad;
   }
   if (curve == LEMSM_BN254_G1) return msm_batch_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, batch, outs, h_scalars);
   return msm_batch_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, batch, outs, h_scalars);

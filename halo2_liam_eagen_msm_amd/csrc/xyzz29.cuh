@@ -202,6 +202,76 @@ struct XYZZ29 {
     F::mul(t, acc.zzz, q.zzz); F::mul(acc.zzz, t, PPP);
   }
 
+  // ---- four lanes per addition (narrow pyramid steps: one dependent addition deep, the chip nearly empty) -------------------
+  // The 14 products of the XYZZ addition have a critical path of four: lane q of a quad computes one product per stage and
+  // DPP quad permutes carry the few values another lane needs (9 moves each).  ~1150 instructions deep instead of ~3300:
+  //   stage 1   q0: U1 = X1 ZZ2    q1: U2 = X2 ZZ1     q2: S1 = Y1 ZZZ2     q3: S2 = Y2 ZZZ1     -> P = U2 - U1 (q0, q1), R = S2 - S1 (q2, q3)
+  //   stage 2   q0: PP = P^2       q1: ZZ1 ZZ2         q2: RR = R^2         q3: ZZZ1 ZZZ2
+  //   stage 3   q0: PPP = P PP     q1: ZZ3 = (..) PP   q2: Q = U1 PP                             -> q2: X3 = RR - PPP - 2Q
+  //   stage 4   q0: S1 PPP                             q2: R (Q - X3)       q3: ZZZ3 = (..) PPP  -> q2: Y3 = R (Q - X3) - S1 PPP
+  // Operands come straight from memory with lane-dependent addresses (no selects for stages 1 and 2); results are stored by the
+  // lane that holds them.  Returns false -- for the whole quad -- when the pair needs the complete addition (an identity operand,
+  // equal or opposite points): the caller lets one lane run add().
+  template <int CTRL>
+  static __device__ __forceinline__ void quad_move(fe& r, const fe& a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (i32)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xf, 0xf, false);
+  }
+  static __device__ __forceinline__ void ld_elem(fe& r, const char* p, u32 k) {
+    const i32* e = reinterpret_cast<const i32*>(p + 36u * k);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = e[i];
+  }
+  static __device__ __forceinline__ void st_elem(char* p, u32 k, const fe& a) {
+    i32* e = reinterpret_cast<i32*>(p + 36u * k);
+#pragma unroll
+    for (int i = 0; i < 9; i++) e[i] = a.l[i];
+  }
+  static __device__ __forceinline__ void sel(fe& r, bool c, const fe& a, const fe& b) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = c ? a.l[i] : b.l[i];
+  }
+  static __device__ __forceinline__ bool add4_mem(const char* pa, const char* pb, char* dst, u32 q) {
+    const bool odd = (q & 1u) != 0, hi = q >= 2u;
+    fe A, B, C, E, r1, x1, D;
+    ld_elem(A, odd ? pb : pa, hi ? 1u : 0u);            // q0: X1, q1: X2, q2: Y1, q3: Y2
+    ld_elem(B, odd ? pa : pb, hi ? 3u : 2u);            // q0: ZZ2, q1: ZZ1, q2: ZZZ2, q3: ZZZ1
+    ld_elem(C, pa, hi ? 3u : 2u);                       // ZZ1 | ZZZ1
+    ld_elem(E, pb, hi ? 3u : 2u);                       // ZZ2 | ZZZ2
+    int sp = (F::limbs_zero(C) || F::limbs_zero(E)) ? 1 : 0;   // the identity is all zeros
+    F::mul(r1, A, B);
+    quad_move<0xB1>(x1, r1);                            // the neighbour's product
+    F::sub(D, x1, r1); F::cneg(D, D, odd);              // q0, q1: P = U2 - U1;  q2, q3: R = S2 - S1
+    fe A2, B2, r2;
+    sel(A2, odd, C, D); sel(B2, odd, E, D);
+    F::mul(r2, A2, B2);                                 // q0: PP, q1: ZZ1 ZZ2, q2: RR, q3: ZZZ1 ZZZ2
+    const int pz = pp_is_zero(r2) ? 1 : 0;
+    sp |= __builtin_amdgcn_update_dpp(0, pz, 0x00, 0xf, 0xf, false);      // q0's verdict on P
+    sp |= __builtin_amdgcn_update_dpp(0, sp, 0xB1, 0xf, 0xf, false);
+    sp |= __builtin_amdgcn_update_dpp(0, sp, 0x4E, 0xf, 0xf, false);      // the same answer in all four lanes
+    if (sp) return false;
+    fe bPP, bU1, A3, r3;
+    quad_move<0x00>(bPP, r2); quad_move<0x00>(bU1, r1);
+    sel(A3, q == 0u, D, r2); sel(A3, q == 2u, bU1, A3);
+    F::mul(r3, A3, bPP);                                // q0: PPP, q1: ZZ3, q2: Q
+    fe bPPP, T, X3, V, bS1, A4, B4, r4, bY, Y3;
+    quad_move<0x00>(bPPP, r3);
+#pragma unroll
+    for (int i = 0; i < 9; i++) T.l[i] = r2.l[i] - bPPP.l[i] - 2 * r3.l[i];
+    F::wnorm(T); F::reduce_small(X3, T);                // q2: X3 = RR - PPP - 2Q, |X3| < 2N
+    F::sub(V, r3, X3);                                  // q2: Q - X3
+    quad_move<0xAA>(bS1, r1);                           // S1
+    sel(A4, q == 0u, bS1, r2); sel(A4, q == 2u, D, A4);
+    sel(B4, q == 2u, V, bPPP);
+    F::mul(r4, A4, B4);                                 // q0: S1 PPP, q2: R (Q - X3), q3: ZZZ3
+    quad_move<0x00>(bY, r4);
+    F::sub(Y3, r4, bY); F::wnorm(Y3);                   // q2: Y3
+    if (q == 1u) st_elem(dst, 2u, r3);
+    if (q == 3u) st_elem(dst, 3u, r4);
+    if (q == 2u) { st_elem(dst, 0u, X3); st_elem(dst, 1u, Y3); }
+    return true;
+  }
+
   // One step of the wave-level inclusive scan over points (GFX9 DPP, the sequence the compiler uses for wave
   // reductions): steps 0..3 fetch the lane 1, 2, 4, 8 places below inside the 16-lane row, step 4 gives rows 1 and 3
   // the last lane of the row below (row_bcast:15), step 5 gives rows 2 and 3 lane 31 (row_bcast:31); a lane without a

@@ -207,6 +207,43 @@ def test_msm_adversarial_shapes(fctx, curve):
     assert canon(curve, ctx.msm(curve.cid, sc, pts)) == canon(curve, cref.msm_naive(curve.cid, sc, pts))
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("c_bits", [0, 4, 8, 11])
+def test_msm_pyramid_quad_additions_special_pairs(ctx, curve, c_bits):
+    """the four-lanes-per-addition form of the narrow pyramid steps (XYZZ29::add4_mem, option pyr_quad) hands every pair it
+    cannot do -- an identity operand, equal points (a doubling), opposite points -- to the complete addition: buckets built so
+    that neighbouring bucket sums ARE equal (the same point under scalars 2k and 2k+1 in every window), opposite (P and -P) or
+    empty, against the oracle and against one lane per addition"""
+    n = 512
+    g = cref.gen_points(curve.cid, 5001, 3)
+    pa = curve.raw_to_affine(g[1].tobytes())
+    neg = np.frombuffer(curve.affine_to_raw(curve.neg(pa)), np.uint64)
+    pts = np.zeros((n, 8), np.uint64); sc = np.zeros((n, 32), np.uint8)
+    width = c_bits if c_bits else 6
+    for i in range(n):
+        k = i % 64
+        if i < 256:    # equal bucket sums: the same point in buckets 2j and 2j + 1 of every window
+            pts[i] = g[0]; digit = (2 * (k // 2) + (k & 1)) % (1 << width) or 1
+        elif i < 448:  # opposite bucket sums
+            pts[i] = g[1] if (k & 1) == 0 else neg; digit = (2 * (k // 2) + (k & 1)) % (1 << width) or 1
+        else:          # sparse: most buckets of the upper windows stay empty
+            pts[i] = g[2]; digit = 1 + (k % 3)
+        v = 0
+        for w in range(0, 250 // width):
+            v |= digit << (w * width)
+        sc[i] = np.frombuffer(int(v % curve.order).to_bytes(32, "little"), np.uint8)
+    exp = canon(curve, cref.best_multiexp(curve.cid, sc, pts, 4))
+    res = []
+    ctx.set_option("window_bits", c_bits)
+    try:
+        for mode in (0, 2):
+            ctx.set_option("pyr_quad", mode)
+            res.append(canon(curve, ctx.msm(curve.cid, sc, pts)))
+    finally:
+        ctx.set_option("window_bits", 0); ctx.set_option("pyr_quad", 0)
+    assert res[0] == exp and res[1] == exp
+
+
 def test_msm_skewed_buckets_all_windows_equal(fctx):
     ctx = fctx
     """all scalars equal with c=16 windows: every window has a single bucket holding all points"""
