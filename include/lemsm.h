@@ -193,7 +193,8 @@ lemsm_ctx* lemsm_node_ctx(lemsm_node* node, int i);
 const char* lemsm_node_last_error(const lemsm_node* node);
 /* bases: n affine points (host), replicated into every GPU once and kept resident (halo2's bases are a fixed SRS) */
 int lemsm_node_set_bases(lemsm_node* node, int curve, const uint64_t* points_affine, size_t n);
-/* best_multiexp(scalars, bases[..n]) over the node */
+/* best_multiexp(scalars, bases[..n]) over the node.  Every GPU uploads one G-th of the scalar vector over its own PCIe link and
+   an in-place all-gather over xGMI completes the copies (the host's memory is read once, not G times). */
 int lemsm_node_msm(lemsm_node* node, const uint8_t* scalars, size_t n, uint64_t out_jacobian[12]);
 /* compute_lhs_witness MSM core over the node (n must equal the number of resident bases, :88) */
 int lemsm_node_lhs_msm(lemsm_node* node, const uint8_t* scalars, size_t n, uint8_t base, uint64_t out_carry[12],
