@@ -269,16 +269,20 @@ __global__ __launch_bounds__(1024) void k_binscan(GroupPlan pl, const u32* __res
   }
 }
 
-template <class Dec, int STG /* entries staged per block: STAGE, 2*STAGE, or 4*STAGE with 1024 threads */, int BS = 256>
+template <class Dec, int STG /* entries staged per block: STAGE, 2*STAGE, or 4*STAGE with 1024 threads */, int BS = 256,
+          bool LEAN = false /* 256-thread blocks, an even number of bins per window: a thread owns two ADJACENT bins (8-byte loads of its
+          counts / claims / bin starts, ONE block scan instead of two), the staged word keeps local bucket and sign where the entry has
+          them (entry = (word & 0xff003fff) + j0), and the store loop is unrolled so that its LDS reads are in flight together */>
 __global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u32* __restrict__ block_counts,
                                                  const u32* __restrict__ bin_start,
                                                  u32* __restrict__ entries, u32 xcd_windows /* 1-D grid, one XCD per window */) {
   static_assert(BS == 256 || BS == 1024, "block size");
   static_assert(STG <= 16384, "jl field is 14 bits");
-  __shared__ u32 delta[BW_MAX];        // global position of a bin's run minus its position in the staging buffer
-  __shared__ u32 lcur[BW_MAX];
+  static_assert(!LEAN || BS == 256, "the lean form is the 256-thread one");
+  __shared__ __align__(8) u32 delta[BW_MAX];        // global position of a bin's run minus its position in the staging buffer
+  __shared__ __align__(8) u32 lcur[BW_MAX];
   __shared__ u32 wsum[16];
-  __shared__ u32 stage[STG];           // jl:14 | local:7 | sign:1 | bin:9  (jl = index inside the block's range)
+  __shared__ u32 stage[STG];           // jl:14 | local:7 | sign:1 | bin:9  (jl = index inside the block's range); LEAN: jl:14 | bin:9 | 0 | local:7 | sign:1
   // Block -> (window, range).  With >= 8 windows (1-D grid of 8 * ceil(gw/8) * nblk1 blocks) all blocks of
   // one window carry the same blockIdx.x % 8, i.e. run on one XCD (guide T1: the label groups blocks by XCD):
   // neighbouring (block, bin) runs of a window are then written through ONE L2 and merge into whole lines --
@@ -344,7 +348,18 @@ __global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u3
   const size_t crow = ((size_t)wl * pl.nblk1 + r) * pl.BW;
   const u32* __restrict__ block_offs = block_counts + (size_t)pl.nblk1 * pl.nbins;   // claimed by the counting kernel's atomics
   u32 total;
-  if constexpr (BS == 256) {
+  if constexpr (LEAN) {
+    // bins 2 tid and 2 tid + 1 (BW is even and <= 512; every table below starts 8-byte aligned and crow, wl * BW are even)
+    const u32 b0 = 2u * tid;
+    const bool h = b0 < pl.BW;
+    const uint2 z2 = make_uint2(0u, 0u);
+    const uint2 cnt = h ? *reinterpret_cast<const uint2*>(block_counts + crow + b0) : z2;
+    const uint2 clm = h ? *reinterpret_cast<const uint2*>(block_offs + crow + b0) : z2;
+    const uint2 bs = h ? *reinterpret_cast<const uint2*>(bin_start + (size_t)wl * pl.BW + b0) : z2;
+    const u32 off0 = block_excl_scan_256(cnt.x + cnt.y, &total, wsum), off1 = off0 + cnt.x;
+    *reinterpret_cast<uint2*>(&delta[b0]) = make_uint2(bs.x + clm.x - off0, bs.y + clm.y - off1);
+    *reinterpret_cast<uint2*>(&lcur[b0]) = make_uint2(off0, off1);
+  } else if constexpr (BS == 256) {
     // up to BW_MAX = 512 bins per window: two bins per thread (tid and tid + 256)
     const bool h0 = tid < pl.BW, h1 = tid + 256u < pl.BW;
     u32 cnt0 = h0 ? block_counts[crow + tid] : 0u, cnt1 = h1 ? block_counts[crow + tid + 256u] : 0u;
@@ -369,13 +384,25 @@ __global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u3
     if (bk[k]) {
       u32 kk = (bk[k] & 0x7fffffffu) - 1u, b = kk >> pl.LB;
       u32 q = atomicAdd(&lcur[b], 1u);
-      stage[q] = (jl0 + jls * (u32)k) | ((kk & lmask) << 14) | ((bk[k] >> 31) << 21) | (b << 22);
+      if constexpr (LEAN) stage[q] = (bk[k] & 0x80000000u) | (jl0 + jls * (u32)k) | (b << 14) | ((kk & lmask) << 24);
+      else stage[q] = (jl0 + jls * (u32)k) | ((kk & lmask) << 14) | ((bk[k] >> 31) << 21) | (b << 22);
     }
   }
   __syncthreads();
-  for (u32 q = tid; q < total; q += BS) {
-    u32 v = stage[q];
-    entries[delta[v >> 22] + q] = (j0 + (v & 0x3fffu)) | (((v >> 14) & 127u) << 24) | (((v >> 21) & 1u) << 31);
+  if constexpr (LEAN) {
+    u32 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const u32 q = tid + (u32)BS * k; v[k] = q < total ? stage[q] : 0u; }
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const u32 q = tid + (u32)BS * k;
+      if (q < total) entries[delta[(v[k] >> 14) & 511u] + q] = (v[k] & 0xff003fffu) + j0;
+    }
+  } else {
+    for (u32 q = tid; q < total; q += BS) {
+      u32 v = stage[q];
+      entries[delta[v >> 22] + q] = (j0 + (v & 0x3fffu)) | (((v >> 14) & 127u) << 24) | (((v >> 21) & 1u) << 31);
+    }
   }
 }
 

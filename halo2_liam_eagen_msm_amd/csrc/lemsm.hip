@@ -114,7 +114,7 @@ struct lemsm_ctx {
   std::unique_ptr<lemsm::host::Pool> pool;        // host tail: per-window work of one call (hostpool.hpp); created on first use
   std::string last_error;
   long opt_host_threads = 0;
-  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0, opt_dw_halves = 0, opt_dw_ntt_lazy = 0, opt_slab_tail = 0, opt_pyr_quad = 0;
+  long opt_window_bits = 0, opt_chunk = 0, opt_tile = 0, opt_field = 0, opt_accum_waves = 0, opt_groups = 0, opt_host_slab_bits = 0, opt_slab_bits = 0, opt_abi_points = 0, opt_stage2x = 0, opt_xcd_windows = 0, opt_entry_ring = 0, opt_validate_points = 0, opt_pyr_fuse = 0, opt_ntt_tiled = 0, opt_ws_canary = 0, opt_binsort = 0, opt_dw_wrap = 0, opt_dw_fuse = 0, opt_dw_kb = 0, opt_merge_slice = 0, opt_merge_wave_th = 0, opt_dbg_repeat = 0, opt_pyr_first2 = 0, opt_dw_reuse = 0, opt_dw_pw_lazy = 0, opt_dw_halves = 0, opt_dw_ntt_lazy = 0, opt_slab_tail = 0, opt_pyr_quad = 0, opt_scatter_lean = 0;
   u32 plan_slab_n = 0;                            // choose_lb: points of a FULL slab of the running call (every slab of a call, the ragged last one too, uses the same bin geometry)
   bool plan_ring = false;                         // make_group_plan: round the accumulate chunk to the entry ring's 16-entry blocks
   const struct HostStage* host_stage = nullptr;   // set by the host-pointer entries for the duration of one call
@@ -519,6 +519,8 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
   const bool first2 = L >= 5 && ctx->opt_pyr_first2 == 1 && nba == 1;
   RoctxRange rg_group("lemsm: window group (digits + sort + accumulate + tail enqueued)");
   // (shared tail: the first slab clears every slab's bucket area, the later ones only the counters)
+  // (r03: clearing the bucket sums on the second queue beside the digit and sort passes was measured and dropped -- the
+  // digit kernel slows down by what the memset takes, 29.6 -> 47.8 us at 2^20: profiles/r03/s_scatter_lean_and_clear_beside_ab.txt)
   HIPCHK(ctx, hipMemsetAsync(ws_base + w.zero_begin, 0, (first2 || slab_k > 0) ? w.zero_bytes_counters : w.zero_bytes, st));
   for (size_t g : w.guards) HIPCHK(ctx, hipMemsetAsync(ws_base + g, 0xA5, WS_GUARD, st));
 
@@ -532,6 +534,8 @@ int run_group(lemsm_ctx* ctx, const Prov& prov, const GroupPlan& pl, u32 nbp, u3
     hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 4 * STAGE, 1024>), g1, dim3(1024), 0, st, dec, pl, w.block_counts, w.bin_start, w.entries, xw);
   else if (pl.spb > STAGE)
     hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, 2 * STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.entries, xw);
+  else if (Prov::Dec::VEC && (pl.BW & 1u) == 0 && ctx->opt_scatter_lean == 1)   // A/B knob (needs an even number of bins per window): 899 us against 880 at 2^24, profiles/r03/s_scatter_lean_and_clear_beside_ab.txt
+    hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE, 256, true>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.entries, xw);
   else
     hipLaunchKernelGGL((k_scatter1<typename Prov::Dec, STAGE>), g1, dim3(256), 0, st, dec, pl, w.block_counts, w.bin_start, w.entries, xw);
   // pass 2 only where a bin holds more than one bucket (LB > 0); with <= 256 buckets per window
@@ -1645,6 +1649,7 @@ int lemsm_set_option(lemsm_ctx* ctx, const char* name, long value) {
   else if (!strcmp(name, "dw_kb")) { if (value < 0 || value > 64) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_kb = value; }
   else if (!strcmp(name, "dw_fuse")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_fuse = value; }
   else if (!strcmp(name, "dw_pw_lazy")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_pw_lazy = value; }
+  else if (!strcmp(name, "scatter_lean")) { if (value < 0 || value > 1) return LEMSM_ERR_BAD_ARG; ctx->opt_scatter_lean = value; }   // 1: k_scatter1 with two adjacent bins per thread (A/B knob: measured no faster)
   else if (!strcmp(name, "pyr_quad")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_pyr_quad = value; }
   else if (!strcmp(name, "slab_tail")) { if (value != 0 && value != 2) return LEMSM_ERR_BAD_ARG; ctx->opt_slab_tail = value; }
   else if (!strcmp(name, "dw_halves")) { if (value != 0 && value != 1) return LEMSM_ERR_BAD_ARG; ctx->opt_dw_halves = value; }
@@ -1762,7 +1767,7 @@ static int msm_batch_entry(lemsm_ctx* ctx, int curve, const void* const* d_scala
     p->opt_accum_waves = ctx->opt_accum_waves; p->opt_groups = ctx->opt_groups; p->opt_slab_bits = ctx->opt_slab_bits; p->opt_abi_points = ctx->opt_abi_points;
     p->opt_stage2x = ctx->opt_stage2x; p->opt_xcd_windows = ctx->opt_xcd_windows; p->opt_entry_ring = ctx->opt_entry_ring; p->opt_pyr_fuse = ctx->opt_pyr_fuse;
     p->opt_ws_canary = ctx->opt_ws_canary; p->opt_binsort = ctx->opt_binsort; p->opt_merge_slice = ctx->opt_merge_slice; p->opt_merge_wave_th = ctx->opt_merge_wave_th;
-    p->opt_pyr_first2 = ctx->opt_pyr_first2; p->opt_host_threads = ctx->opt_host_threads; p->plan_world = ctx->plan_world; p->opt_slab_tail = ctx->opt_slab_tail; p->opt_pyr_quad = ctx->opt_pyr_quad;
+    p->opt_pyr_first2 = ctx->opt_pyr_first2; p->opt_host_threads = ctx->opt_host_threads; p->plan_world = ctx->plan_world; p->opt_slab_tail = ctx->opt_slab_tail; p->opt_pyr_quad = ctx->opt_pyr_quad; p->opt_scatter_lean = ctx->opt_scatter_lean;
   }
   if (curve == LEMSM_BN254_G1) return msm_batch_t<host::FqParams64, GqLazy>(ctx, curve, d_scalars, d_points, n, batch, outs, h_scalars);
   return msm_batch_t<host::FrParams64, GrLazy>(ctx, curve, d_scalars, d_points, n, batch, outs, h_scalars);

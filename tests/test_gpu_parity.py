@@ -180,6 +180,25 @@ def test_msm_window_and_chunk_sweep(fctx, c_bits, chunk):
         ctx.set_option("window_bits", 0); ctx.set_option("chunk", 0); ctx.set_option("tile", 0)
 
 
+@pytest.mark.parametrize("knobs", [{"scatter_lean": 1}], ids=str)
+@pytest.mark.parametrize("n,c_bits", [(700, 0), (5000, 9), (70000, 0), (70000, 16), (300000, 17)])
+def test_msm_scatter_form_knob_equals_default(ctx, knobs, n, c_bits):
+    """A/B knob of r03: k_scatter1 with two ADJACENT bins per thread (8-byte loads of the counts / claims / bin starts, one block
+    scan, unrolled store loop) gives the same group element as the default form (bins tid and tid + 256, two block scans)"""
+    curve = pyref.BN254_G1
+    pts = cref.gen_points(curve.cid, 77, n)
+    sc = cref.gen_scalars(curve.cid, 78, n)
+    exp = canon(curve, cref.best_multiexp(curve.cid, sc, pts, 8))
+    ctx.set_option("window_bits", c_bits)
+    try:
+        assert canon(curve, ctx.msm(curve.cid, sc, pts)) == exp
+        for k, v in knobs.items(): ctx.set_option(k, v)
+        assert canon(curve, ctx.msm(curve.cid, sc, pts)) == exp
+    finally:
+        ctx.set_option("window_bits", 0)
+        for k in knobs: ctx.set_option(k, 0)
+
+
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 def test_msm_adversarial_shapes(fctx, curve):
     ctx = fctx

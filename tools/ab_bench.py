@@ -18,7 +18,7 @@ ds = ctx.to_device(sc)
 q = np.zeros(8, np.uint64); fp = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 q[:4] = np.frombuffer(((1 << 256) % fp).to_bytes(32, "little"), np.uint64); q[4:] = np.frombuffer(((2 << 256) % fp).to_bytes(32, "little"), np.uint64)
 dp = ctx.gen_walk(0, q, n)
-ALL = ["window_bits", "chunk", "tile", "field", "accum_waves", "merge_slice", "merge_wave_th", "abi_points", "stage2x", "xcd_windows", "entry_ring", "binsort"]
+ALL = ["window_bits", "chunk", "tile", "field", "accum_waves", "merge_slice", "merge_wave_th", "abi_points", "stage2x", "xcd_windows", "entry_ring", "binsort", "scatter_lean"]
 res = {i: [] for i in range(len(variants))}
 ref = None
 for rnd in range(int(os.environ.get("AB_ROUNDS", "4"))):
