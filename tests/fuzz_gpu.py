@@ -162,7 +162,7 @@ def main(secs=None, seed=None):
     head = int.from_bytes(bytes.fromhex(chains["omega_pow"]["head"]), "little")
     O = dv.DivisorOracle(pyref.GRUMPKIN, dv.FrFft(pyref.GRUMPKIN.fp, head * pow(1 << 256, -1, pyref.GRUMPKIN.fp) % pyref.GRUMPKIN.fp))
     t0 = time.time(); cases = 0; kinds_seen = {}
-    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "merge_slice", "merge_wave_th", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows", "ws_canary", "pyr_fuse", "pyr_first2", "binsort", "dw_wrap", "dw_fuse", "dw_reuse", "dw_pw_lazy", "slab_tail", "dw_ntt_lazy", "dw_halves", "pyr_quad"]
+    names = ["window_bits", "chunk", "tile", "field", "abi_points", "slab_bits", "merge_slice", "merge_wave_th", "accum_waves", "host_slab_bits", "groups", "entry_ring", "xcd_windows", "ws_canary", "pyr_fuse", "pyr_first2", "binsort", "dw_wrap", "dw_fuse", "dw_reuse", "dw_pw_lazy", "slab_tail", "dw_ntt_lazy", "dw_halves", "pyr_quad", "scatter_lean"]
     while time.time() - t0 < secs:
         curve = CURVES[int(rng.integers(0, 2))]
         opts = {"window_bits": int(rng.choice([0, 0, 2, 3, 5, 8, 11, 13, 16, 17])), "chunk": int(rng.choice([0, 0, 1, 3, 17, 64, 300])),
@@ -172,7 +172,7 @@ def main(secs=None, seed=None):
                 "groups": 0, "entry_ring": int(rng.integers(0, 2)), "xcd_windows": int(rng.integers(0, 2)),
                 "ws_canary": int(rng.random() < 0.3), "pyr_fuse": int(rng.choice([0, 0, 1, 2])), "pyr_first2": int(rng.random() < 0.3),
                 "binsort": int(rng.choice([0, 0, 2, 3, 40, 700])), "dw_wrap": int(rng.choice([0, 0, 2])), "dw_fuse": int(rng.choice([0, 0, 2])), "dw_reuse": int(rng.choice([0, 0, 2])), "dw_pw_lazy": int(rng.choice([0, 0, 1])),
-                "slab_tail": int(rng.choice([0, 0, 2])), "dw_ntt_lazy": int(rng.choice([0, 0, 1])), "dw_halves": int(rng.choice([0, 0, 1])), "pyr_quad": int(rng.choice([0, 0, 2]))}     # 2: tiled pass 2 only; > 2: a bin capacity that splits the bins between both paths
+                "slab_tail": int(rng.choice([0, 0, 2])), "dw_ntt_lazy": int(rng.choice([0, 0, 1])), "dw_halves": int(rng.choice([0, 0, 1])), "pyr_quad": int(rng.choice([0, 0, 2])), "scatter_lean": int(rng.choice([0, 1]))}     # 2: tiled pass 2 only; > 2: a bin capacity that splits the bins between both paths
         host_entry = rng.random() < 0.5
         if not host_entry:
             opts["groups"] = int(rng.choice([0, 0, 2, 3]))     # pipelined window groups: device-pointer entries only
