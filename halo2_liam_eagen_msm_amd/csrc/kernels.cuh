@@ -205,10 +205,25 @@ __global__ __launch_bounds__(256) void k_count1(Dec dec, GroupPlan pl, u32* __re
     bk[k] = 0;
     if (j < j1) dec.get(j, w, pl, bk[k], sign);
   }
+  // At most 16 bins per window (negabase digits: bins are buckets, base - 1 of them): a block's 4096 atomics on 15 addresses
+  // serialise in the LDS (tools/ubench/lds_rank_rates.hip: 2.2 lane-operations per clock at 8 addresses against 6.0 at 512),
+  // so lane l counts in copy l % 16 of the histogram and the copies are added up afterwards.
+  const bool few = pl.BW <= 16u;
+  const u32 rep = few ? (tid & 15u) << 4 : 0u;
 #pragma unroll
   for (int k = 0; k < PER; k++)
-    if (bk[k]) atomicAdd(&hist[(bk[k] - 1u) >> pl.LB], 1u);
+    if (bk[k]) atomicAdd(&hist[rep + ((bk[k] - 1u) >> pl.LB)], 1u);
   __syncthreads();
+  if (few) {
+    u32 c = 0;
+    if (tid < 16u) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) c += hist[r * 16 + tid];
+    }
+    __syncthreads();
+    if (tid < 16u) hist[tid] = c;
+    __syncthreads();
+  }
   if (tid < pl.BW) {
     u32 cnt = hist[tid];
     const size_t slot = ((size_t)wl * pl.nblk1 + r) * pl.BW + tid;
@@ -348,6 +363,23 @@ __global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u3
   const size_t crow = ((size_t)wl * pl.nblk1 + r) * pl.BW;
   const u32* __restrict__ block_offs = block_counts + (size_t)pl.nblk1 * pl.nbins;   // claimed by the counting kernel's atomics
   u32 total;
+  // At most 16 bins per window (negabase digits): 16 cursors per bin, lane l ranks in copy l % 16, so that the block's 4096 returning
+  // atomics spread over 16 x BW addresses instead of serialising on BW (see k_count1).  The copies' counts are taken here (one more
+  // pass of non-returning atomics) and scanned bin-major: copy r of bin b owns the part [scan(b, r), scan(b, r + 1)) of the bin's run.
+  const bool few = !Dec::VEC && BS == 256 && !LEAN && pl.BW <= 16u;
+  if (few) {
+    lcur[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+      if (bk[k]) atomicAdd(&lcur[((((bk[k] & 0x7fffffffu) - 1u) >> pl.LB) << 4) | (tid & 15u)], 1u);
+    __syncthreads();
+    const u32 v = lcur[tid];
+    const u32 off = block_excl_scan_256(v, &total, wsum);
+    lcur[tid] = off;
+    const u32 b = tid >> 4;
+    if ((tid & 15u) == 0 && b < pl.BW) delta[b] = bin_start[wl * pl.BW + b] + block_offs[crow + b] - off;
+  } else
   if constexpr (LEAN) {
     // bins 2 tid and 2 tid + 1 (BW is even and <= 512; every table below starts 8-byte aligned and crow, wl * BW are even)
     const u32 b0 = 2u * tid;
@@ -383,7 +415,7 @@ __global__ __launch_bounds__(BS) void k_scatter1(Dec dec, GroupPlan pl, const u3
   for (int k = 0; k < PER; k++) {
     if (bk[k]) {
       u32 kk = (bk[k] & 0x7fffffffu) - 1u, b = kk >> pl.LB;
-      u32 q = atomicAdd(&lcur[b], 1u);
+      u32 q = atomicAdd(&lcur[few ? ((b << 4) | (tid & 15u)) : b], 1u);
       if constexpr (LEAN) stage[q] = (bk[k] & 0x80000000u) | (jl0 + jls * (u32)k) | (b << 14) | ((kk & lmask) << 24);
       else stage[q] = (jl0 + jls * (u32)k) | ((kk & lmask) << 14) | ((bk[k] >> 31) << 21) | (b << 22);
     }

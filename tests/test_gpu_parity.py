@@ -655,6 +655,23 @@ def test_lhs_matches_oracle(fctx, curve, base, n):
     assert canon(curve, carry) == canon(curve, ctx.msm(curve.cid, sc, pts_aff))
 
 
+@pytest.mark.parametrize("base,n", [(16, 70000), (17, 66000), (3, 66000), (18, 66000)])
+def test_lhs_few_bins_replicated_cursors_many_blocks(ctx, base, n):
+    """r03: with at most 16 buckets per digit position (base <= 17) pass 1 counts and ranks in 16 copies of its LDS cursors
+    (k_count1, k_scatter1); base 18 (17 bins) takes the single-cursor form.  Several pass-1 blocks per position, all carries."""
+    curve = pyref.GRUMPKIN
+    seed_pts = cref.gen_points(curve.cid, 90, 64)
+    pts_aff = np.tile(seed_pts, ((n + 63) // 64, 1))[:n].copy()
+    sc = cref.gen_scalars(curve.cid, 91 + n, n, half=True)
+    pts = cref.aff_to_jac(curve.cid, pts_aff)
+    ecarry, ecarries = cref.lhs_msm(curve.cid, sc, pts, base)
+    carry, carries = ctx.lhs_msm(curve.cid, sc, pts, base)
+    assert canon(curve, carry) == canon(curve, ecarry)
+    assert carries.shape == ecarries.shape
+    for i in range(carries.shape[0]):
+        assert canon(curve, carries[i]) == canon(curve, ecarries[i]), i
+
+
 def test_lhs_reference_test_shape(fctx):
     ctx = fctx
     """lhs_test itself: Grumpkin, base 5, one (scalar, point) pair replicated; here n = 2000"""
