@@ -107,7 +107,7 @@ size_t lemsm_last_truncated_count(const lemsm_ctx* ctx);
    "dw_fuse" (divisor witness: 0 = the first forward transform pass of a level gathers its
    input from the coefficient arrays and the last inverse pass scatters into them; 2 = separate load / store kernels:
    A/B knob), "dw_pw_lazy" (divisor witness: 1 = the pointwise numerators in the lazy 29-bit field -- 12 cheaper products, paid back by the
-   conversions around them: measured no faster; 0 = strict field: A/B knob), "pyr_quad" (bucket-reduction pyramid, lazy arithmetic: 0 = steps that leave most of the chip without a wave -- and the fused last steps -- run four lanes per addition (one product per lane and stage, DPP quad exchanges: ~2.6x shallower); 2 = one lane per addition: A/B knob), "slab_tail" (calls of more than one slab of points -- more than 2^24, or option slab_bits: 0 = every slab accumulates into a bucket area of its own and the call runs one bucket reduction and leaves one block of records (up to 8 slabs); 2 = a reduction per slab, the records added on the host: A/B knob), "dw_halves" (divisor witness: 1 = the pointwise chain of a level runs as two halves of its nodes on two queues, one half's batched inversion beside the other half's numerators: measured no faster, profiles/r03/k_halves_trace.txt; 0 = one chain: A/B knob), "dw_ntt_lazy" (divisor witness: 1 = the butterflies of the LDS-tiled transforms in the lazy 29-bit field, twiddles from a second table -- measured 1 % slower: the strict product is 128 multiply-adds here, the lazy one 162 plus carry passes; 0 = strict field: A/B knob), "dw_reuse" (divisor witness: 0 = a level transforms its children onto the odd half of its domain only and reads the even half from the level
+   conversions around them: measured no faster; 0 = strict field: A/B knob), "scatter_lean" (pass 1 of the bucket sort: 1 = a thread of k_scatter1 owns two adjacent bins, one block scan, unrolled store loop -- measured no faster, profiles/r03/s_scatter_lean_and_clear_beside_ab.txt; 0 = bins tid and tid + 256: A/B knob), "pyr_quad" (bucket-reduction pyramid, lazy arithmetic: 0 = steps that leave most of the chip without a wave -- and the fused last steps -- run four lanes per addition (one product per lane and stage, DPP quad exchanges: ~2.6x shallower); 2 = one lane per addition: A/B knob), "slab_tail" (calls of more than one slab of points -- more than 2^24, or option slab_bits: 0 = every slab accumulates into a bucket area of its own and the call runs one bucket reduction and leaves one block of records (up to 8 slabs); 2 = a reduction per slab, the records added on the host: A/B knob), "dw_halves" (divisor witness: 1 = the pointwise chain of a level runs as two halves of its nodes on two queues, one half's batched inversion beside the other half's numerators: measured no faster, profiles/r03/k_halves_trace.txt; 0 = one chain: A/B knob), "dw_ntt_lazy" (divisor witness: 1 = the butterflies of the LDS-tiled transforms in the lazy 29-bit field, twiddles from a second table -- measured 1 % slower: the strict product is 128 multiply-adds here, the lazy one 162 plus carry passes; 0 = strict field: A/B knob), "dw_reuse" (divisor witness: 0 = a level transforms its children onto the odd half of its domain only and reads the even half from the level
    below's evaluations, 2 = whole transforms: A/B knob), "dw_wrap" (divisor witness: 0 = levels whose longest part
    has 2^k + 1 coefficients run on 2^k-point transforms, the folded top coefficient recovered from the value at x = 0;
    2 = always the next power of two: A/B knob), "ws_canary" (1 = debug: every sub-buffer of the MSM workspace is followed by a 256-byte guard that is
